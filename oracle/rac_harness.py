@@ -1,0 +1,181 @@
+"""RAC harness — "reference-as-composed" (SURVEY.md §0.2 / §8c).  TEST INFRASTRUCTURE ONLY.
+
+Imports the *reference's own* modules from /root/reference (read-only, never copied) so that the
+oracle restatement (oracle/setok_oracle.py) can be pinned against the reference's real arithmetic
+and so that golden vectors (tests/golden/) can be generated.  This file only runs inside the build
+container: /root/reference does not exist on the GPU box, and nothing under tests/ -m gpu, smoke()
+or bench.py imports it.
+
+Two import shims are needed because the reference pins older third-party packages
+(pyproject.toml:15-26) than the ones installed here:
+  * shim 1: `timm.models.layers.DropPath` is imported (tokenizer.py:7, module.py:7) but never
+    instantiated when drop_path == 0.0 (module.py:82) -> identity stub module.
+  * shim 2: module.py:16-21 imports `apply_chunking_to_forward`, `prune_linear_layer`,
+    `find_pruneable_heads_and_indices` from transformers.modeling_utils (moved / removed upstream).
+
+The harness supplies exactly two repairs to make the reference's forward composable, both
+documented in SURVEY.md §0.2:
+  * D1: SetokTokenizer.forward is only shape-consistent for ONE image's (N, C) features, so the
+    batch is a python loop over images;
+  * D2: inter_encoder needs a (1, L, C) input -> one unsqueeze / squeeze.
+Everything else (CLIPVisionTower.forward, PositionalEncoding2D.forward, cluster_dpc_knn,
+group_encoding, Block.forward, out) is the reference's code executed unmodified.
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import importlib.util
+import math
+import os
+import sys
+import tempfile
+import types
+
+import torch
+
+REF_ROOT = os.environ.get("SETOK_REFERENCE_ROOT", "/root/reference")
+_SETOK_DIR = os.path.join(REF_ROOT, "src", "model", "setok")
+_PKG = "_rac_setok"
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(_SETOK_DIR, "tokenizer.py"))
+
+
+def _install_shims() -> None:
+    if "timm" not in sys.modules:
+        class DropPath(torch.nn.Identity):
+            def __init__(self, drop_prob: float = 0.0, *a, **k):
+                super().__init__()
+        for name in ("timm", "timm.models", "timm.models.layers"):
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None, is_package=True)
+            m.__path__ = []
+            sys.modules[name] = m
+        sys.modules["timm"].models = sys.modules["timm.models"]
+        sys.modules["timm.models"].layers = sys.modules["timm.models.layers"]
+        sys.modules["timm.models.layers"].DropPath = DropPath
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    for name in ("apply_chunking_to_forward", "prune_linear_layer"):
+        if not hasattr(mu, name):
+            setattr(mu, name, getattr(pu, name))
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        def find_pruneable_heads_and_indices(*a, **k):
+            raise NotImplementedError("removed upstream; only used by prune_heads (module.py:397-405)")
+        mu.find_pruneable_heads_and_indices = find_pruneable_heads_and_indices
+
+
+def load_reference():
+    """Load utils/module/clip_encoder/tokenizer from the reference by file path as a synthetic
+    package (bypasses setok/__init__.py, which drags in timm ViT / diffusers / diffdist)."""
+    if _PKG + ".tokenizer" in sys.modules:
+        return sys.modules[_PKG + ".tokenizer"], sys.modules[_PKG + ".module"]
+    if not reference_available():
+        raise FileNotFoundError(f"reference not found under {REF_ROOT}")
+    _install_shims()
+    pkg = types.ModuleType(_PKG)
+    pkg.__path__ = [_SETOK_DIR]
+    pkg.__spec__ = importlib.machinery.ModuleSpec(_PKG, loader=None, is_package=True)
+    sys.modules[_PKG] = pkg
+    mods = {}
+    for name in ("utils", "module", "clip_encoder", "tokenizer"):
+        spec = importlib.util.spec_from_file_location(f"{_PKG}.{name}", os.path.join(_SETOK_DIR, f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"{_PKG}.{name}"] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods["tokenizer"], mods["module"]
+
+
+def make_clip_dir(hidden: int, layers: int, heads: int, mlp: int, image_size: int, patch: int,
+                  seed: int = 0, out_dir: str | None = None) -> str:
+    """Seeded random-init HF CLIPVisionModel saved to a directory AutoModel/AutoProcessor can load
+    (no pretrained weights and no network exist here)."""
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel
+    out_dir = out_dir or tempfile.mkdtemp(prefix="rac_clip_siglip_")  # builder.py:19 wants 'siglip' in the name
+    cfg = CLIPVisionConfig(hidden_size=hidden, intermediate_size=mlp, num_hidden_layers=layers,
+                           num_attention_heads=heads, image_size=image_size, patch_size=patch,
+                           projection_dim=hidden)
+    torch.manual_seed(seed)
+    model = CLIPVisionModel(cfg).eval()
+    model.save_pretrained(out_dir)
+    CLIPImageProcessor(size={"shortest_edge": image_size},
+                       crop_size={"height": image_size, "width": image_size}).save_pretrained(out_dir)
+    return out_dir
+
+
+def build_reference_tokenizer(clip_dir: str, *, hidden_dim: int, token_feat_dim: int, nheads: int = 2,
+                              dim_feedforward: int = 4096, min_cluster_num: int = 64,
+                              threshold: float = 0.5, select_layer: int = -2, head_seed: int = 1,
+                              inner_cluster_layers: int = 2, intra_cluster_layers: int = 2):
+    tok_mod, _ = load_reference()
+    torch.manual_seed(head_seed)
+    tok = tok_mod.SetokTokenizer(vision_tower=clip_dir, mm_vision_select_layer=select_layer,
+                                 hidden_dim=hidden_dim, token_feat_dim=token_feat_dim, nheads=nheads,
+                                 dim_feedforward=dim_feedforward, min_cluster_num=min_cluster_num,
+                                 threshold=threshold, inner_cluster_layers=inner_cluster_layers,
+                                 intra_cluster_layers=intra_cluster_layers)
+    return tok.eval()
+
+
+class FixedNoise:
+    """Context manager replacing torch.rand (tokenizer.py:91) by a caller-supplied noise vector so
+    the density tie-break noise is an explicit, recorded input instead of global RNG state."""
+
+    def __init__(self, noise: torch.Tensor | None):
+        self.noise = noise
+
+    def __enter__(self):
+        self._orig = torch.rand
+        noise = self.noise
+
+        def fake_rand(*shape, **kw):
+            if len(shape) == 1 and not isinstance(shape[0], int):
+                shape = tuple(shape[0])
+            if noise is None:
+                return torch.zeros(*shape, dtype=kw.get("dtype", torch.float32))
+            assert tuple(shape) == tuple(noise.shape), (shape, noise.shape)
+            return noise.to(kw.get("dtype", torch.float32)).clone()
+        torch.rand = fake_rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+        return False
+
+
+@torch.no_grad()
+def rac_head_single(tok, feats_nc: torch.Tensor, k=None, threshold=None, token_mask=None,
+                    noise: torch.Tensor | None = None, return_stages: bool = False):
+    """tokenizer.py:162-180 on ONE image's (N, C) tower features (repair D1), with the D2 unsqueeze."""
+    x = feats_nc.unsqueeze(0)                                   # tokenizer.py:162
+    B, hw, C = x.shape                                          # :163
+    h = w = int(math.sqrt(x.shape[1]))                          # :164
+    pos_emb = tok.position_embedding(x.reshape(B, h, w, C))     # :165-166 (rearrange == reshape)
+    x = x + pos_emb.reshape(B, hw, C)                           # :167-168
+    x = x.squeeze(0)                                            # :169
+    _threshold = threshold if threshold else tok.threshold     # :171
+    _k = k if k else tok.min_cluster_num                        # :172
+    with FixedNoise(noise):
+        index_down, idx_cluster, score = tok.cluster_dpc_knn(x, _k, token_mask, _threshold)  # :174
+    centers = x[index_down, :]                                  # :177
+    group = tok.group_encoding(x, centers, idx_cluster)         # :178
+    inter = tok.inter_encoder(group.unsqueeze(0)).squeeze(0)    # :179 + repair D2
+    out = tok.out(inter)                                        # :180
+    if return_stages:
+        return dict(x=x, index_down=index_down, idx_cluster=idx_cluster, score=score,
+                    group=group, inter=inter, tokens=out)
+    return out, idx_cluster, score
+
+
+@torch.no_grad()
+def rac_forward(tok, images: torch.Tensor, k=None, threshold=None, noise=None, return_stages=False):
+    """Tower on the batch (clip_encoder.py:50-62), then the per-image head loop."""
+    feats = tok.image_feature_encoder(images)                   # tokenizer.py:161
+    outs = []
+    for i in range(feats.shape[0]):
+        nz = None if noise is None else noise[i]
+        outs.append(rac_head_single(tok, feats[i], k=k, threshold=threshold, noise=nz,
+                                    return_stages=return_stages))
+    return feats, outs

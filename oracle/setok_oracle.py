@@ -1,0 +1,440 @@
+"""CPU oracle for the SeTok `encode_images` hot path.  TEST INFRASTRUCTURE — NOT A PRODUCT PATH.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module; the
+product (setok_amd/) never does, and fails loudly when the HIP library is missing.
+
+This is a from-scratch restatement (torch-CPU as the array library, fp32 by default, fp64 for
+decision-margin analysis) of the arithmetic of the reference's path.  Every function cites the
+reference file:line it follows (paths relative to /root/reference/).  It is pinned against the
+reference itself ("RAC", oracle/rac_harness.py) by tests/test_oracle_vs_reference.py in the build
+container, and against the committed golden vectors in tests/golden/ everywhere.
+
+Third-party arithmetic on the path: the ViT tower is HuggingFace `transformers`
+CLIPVisionModel (pinned transformers==4.46.3 in the reference's pyproject.toml:18, 5.15.0 installed
+here; eager attention path, same math).  It is restated in `clip_vit_forward` from the published
+CLIP ViT algorithm and pinned against the installed HF implementation through the reference's own
+call site (src/model/setok/clip_encoder.py:50-62).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+TOWER_PREFIX = "image_feature_encoder.vision_tower."
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class VitConfig:
+    """Subset of HF CLIPVisionConfig the tower arithmetic depends on."""
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    image_size: int = 224
+    patch_size: int = 14
+    layer_norm_eps: float = 1e-5
+    num_channels: int = 3
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def num_patches(self) -> int:
+        return self.grid * self.grid
+
+
+@dataclass
+class HeadConfig:
+    """ctor kwargs of SetokTokenizer (src/model/setok/tokenizer.py:14-34) that affect arithmetic."""
+    hidden_dim: int = 1024
+    token_feat_dim: int = 4096
+    min_cluster_num: int = 64
+    threshold: float = 0.5
+    nheads: int = 2
+    dim_feedforward: int = 4096
+    inner_cluster_layers: int = 2
+    intra_cluster_layers: int = 2
+    mm_vision_select_layer: int = -2
+    mm_vision_select_feature: str = "patch"
+
+
+def normalise_tower_keys(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """transformers 4.46 names tower params `vision_tower.vision_model.*`, 5.x `vision_tower.*`."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith(TOWER_PREFIX + "vision_model."):
+            k = TOWER_PREFIX + k[len(TOWER_PREFIX + "vision_model."):]
+        out[k] = v
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 — the ViT tower (third-party HF CLIP arithmetic; call site clip_encoder.py:50-62)
+# ----------------------------------------------------------------------------------------------
+def quick_gelu(x: Tensor) -> Tensor:
+    """HF `quick_gelu` activation of CLIP's MLP: x * sigmoid(1.702 x)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def clip_vit_hidden_states(sd: Dict[str, Tensor], cfg: VitConfig, images: Tensor,
+                           n_layers: Optional[int] = None) -> List[Tensor]:
+    """HF CLIPVisionModel(images, output_hidden_states=True).hidden_states, restated.
+
+    hidden_states[0] is the embedding output *after* pre_layrnorm, hidden_states[i] the output of
+    encoder layer i (post_layernorm is never applied to hidden states)."""
+    p = TOWER_PREFIX
+    C, H, dh = cfg.hidden_size, cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    B = images.shape[0]
+    w = sd[p + "embeddings.patch_embedding.weight"]
+    x = F.conv2d(images.to(w.dtype), w, bias=None, stride=cfg.patch_size)        # (B, C, g, g)
+    x = x.flatten(2).transpose(1, 2)                                                # (B, N, C)
+    cls = sd[p + "embeddings.class_embedding"].expand(B, 1, -1)
+    x = torch.cat([cls, x], dim=1) + sd[p + "embeddings.position_embedding.weight"][None]
+    x = F.layer_norm(x, (C,), sd[p + "pre_layrnorm.weight"], sd[p + "pre_layrnorm.bias"], cfg.layer_norm_eps)
+    hs = [x]
+    L = cfg.num_hidden_layers if n_layers is None else n_layers
+    scale = dh ** -0.5
+    for i in range(L):
+        q = p + f"encoder.layers.{i}."
+        y = F.layer_norm(x, (C,), sd[q + "layer_norm1.weight"], sd[q + "layer_norm1.bias"], cfg.layer_norm_eps)
+        T = y.shape[1]
+        qh = F.linear(y, sd[q + "self_attn.q_proj.weight"], sd[q + "self_attn.q_proj.bias"]).view(B, T, H, dh).transpose(1, 2)
+        kh = F.linear(y, sd[q + "self_attn.k_proj.weight"], sd[q + "self_attn.k_proj.bias"]).view(B, T, H, dh).transpose(1, 2)
+        vh = F.linear(y, sd[q + "self_attn.v_proj.weight"], sd[q + "self_attn.v_proj.bias"]).view(B, T, H, dh).transpose(1, 2)
+        att = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) * scale, dim=-1)
+        a = torch.matmul(att, vh).transpose(1, 2).reshape(B, T, C)
+        x = x + F.linear(a, sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"])
+        y = F.layer_norm(x, (C,), sd[q + "layer_norm2.weight"], sd[q + "layer_norm2.bias"], cfg.layer_norm_eps)
+        y = quick_gelu(F.linear(y, sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"]))
+        x = x + F.linear(y, sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"])
+        hs.append(x)
+    return hs
+
+
+def layers_needed(cfg: VitConfig, select_layer: int) -> int:
+    """hidden_states has L+1 entries; index `select_layer` needs this many encoder layers."""
+    idx = select_layer if select_layer >= 0 else cfg.num_hidden_layers + 1 + select_layer
+    if not 0 <= idx <= cfg.num_hidden_layers:
+        raise IndexError(f"select_layer {select_layer} out of range for {cfg.num_hidden_layers} layers")
+    return idx
+
+
+def tower_forward(sd: Dict[str, Tensor], cfg: VitConfig, images: Tensor, select_layer: int = -2,
+                  select_feature: str = "patch") -> Tensor:
+    """CLIPVisionTower.forward + feature_select (clip_encoder.py:40-62): hidden_states[select_layer],
+    drop token 0 for 'patch', keep for 'cls_patch', ValueError otherwise; cast back to input dtype."""
+    n = layers_needed(cfg, select_layer)
+    feats = clip_vit_hidden_states(sd, cfg, images, n_layers=n)[n]
+    if select_feature == "patch":
+        feats = feats[:, 1:]
+    elif select_feature != "cls_patch":
+        raise ValueError(f"Unexpected select feature: {select_feature}")
+    return feats.to(images.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# a2 — PositionalEncoding2D (module.py:105-146, utils.py:5-10)
+# ----------------------------------------------------------------------------------------------
+def pos_encoding_2d(h: int, w: int, C: int, dtype=torch.float32) -> Tensor:
+    """(h*w, C) table: channels [0,ch) encode the row index, [ch,2ch) the column index, each as
+    interleaved (sin, cos) of pos * inv_freq; cropped to C (module.py:112-145)."""
+    ch = int(math.ceil(C / 4) * 2)                                                  # module.py:112
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))              # :114
+    def emb1d(n):
+        s = torch.einsum("i,j->ij", torch.arange(n, dtype=inv_freq.dtype), inv_freq)  # :131-134
+        return torch.stack((s.sin(), s.cos()), dim=-1).flatten(-2, -1)             # utils.py:9-10
+    emb = torch.zeros((h, w, ch * 2), dtype=dtype)                                  # :137-141
+    emb[:, :, :ch] = emb1d(h).unsqueeze(1).to(dtype)                                # :142 (row index)
+    emb[:, :, ch:2 * ch] = emb1d(w).to(dtype)                                       # :143 (col index)
+    return emb[:, :, :C].reshape(h * w, C)                                          # :145
+
+
+# ----------------------------------------------------------------------------------------------
+# a3 — cluster_dpc_knn (tokenizer.py:78-121)
+# ----------------------------------------------------------------------------------------------
+def pairwise_dist(x: Tensor) -> Tensor:
+    """torch.cdist(x, x) default compute mode (tokenizer.py:82): for more than 25 rows the matmul
+    form on augmented vectors [-2x, |x|^2, 1]·[x, 1, |x|^2]^T, clamp_min(0), sqrt (hence a diagonal
+    that is not exactly 0 and a matrix that is not bitwise symmetric — SURVEY.md §7 "hard parts");
+    for <= 25 rows the direct sqrt(sum (a-b)^2)."""
+    N = x.shape[0]
+    if N > 25:
+        n = x.pow(2).sum(-1, keepdim=True)
+        one = torch.ones_like(n)
+        a = torch.cat([x.mul(-2), n, one], dim=-1)
+        b = torch.cat([x, one, n], dim=-1)
+        return a.matmul(b.t()).clamp_min_(0).sqrt_()
+    d = x[:, None, :] - x[None, :, :]
+    return d.pow(2).sum(-1).sqrt()
+
+
+@dataclass
+class ClusterResult:
+    index_down: Tensor      # (L,) int64 — centre token indices, ascending
+    idx_cluster: Tensor     # (N,) int64 — cluster id of each token
+    score: Tensor           # (1, N)
+    density: Tensor         # (N,)
+    delta: Tensor           # (N,)
+    dist: Tensor            # (N, N) scaled distance matrix (after token_mask, if any)
+    fallback: bool          # True when no score exceeded the threshold (topk branch, :104-107)
+
+
+def cluster_dpc_knn(x: Tensor, k: int, threshold: float, min_cluster_num: int,
+                    token_mask: Optional[Tensor] = None, noise: Optional[Tensor] = None) -> ClusterResult:
+    """DPC-kNN exactly as tokenizer.py:78-121 composes it, with the density tie-break noise
+    (`torch.rand(N) * 1e-6`, :91) as an explicit input (None == zeros)."""
+    N, C = x.shape
+    dist = pairwise_dist(x) / (C ** 0.5)                                            # :82
+    if token_mask is not None:                                                      # :84-86
+        tm = token_mask > 0
+        dist = dist * tm[None, :] + (dist.max() + 1) * (~tm[None, :])
+    nearest, _ = torch.topk(dist, k=k, dim=-1, largest=False)                       # :88 (self included)
+    density = (-(nearest ** 2).mean(dim=-1)).exp()                                  # :90
+    if noise is not None:
+        density = density + noise.to(density.dtype) * 1e-6                          # :91
+    if token_mask is not None:
+        density = density * tm                                                      # :93-94
+    mask = (density[None, :] > density[:, None]).to(x.dtype)                        # :96-97  mask[i,j] = rho_j > rho_i
+    dist_max = dist.flatten(1).max(dim=-1)[0][None, None]                           # :98  (1,1,N): row-j max, indexed by LAST axis
+    delta, _ = (dist * mask + dist_max * (1 - mask)).min(dim=-1)                    # :99  -> (1, N)
+    score = delta * density                                                         # :101 -> (1, N)
+    index_down = torch.nonzero(score.reshape(-1) > threshold).reshape(-1)           # :103
+    fallback = index_down.numel() == 0
+    if fallback:                                                                    # :104-107
+        _, index_down = torch.topk(score, k=min_cluster_num, dim=-1)
+        index_down = torch.sort(index_down).values.reshape(-1)
+    idx_cluster = dist[index_down, :].argmin(dim=0)                                 # :111-113 rows = centres
+    idx_cluster[index_down] = torch.arange(index_down.numel())                      # :117-119
+    return ClusterResult(index_down, idx_cluster, score, density, delta.reshape(-1), dist, fallback)
+
+
+def cluster_fragile_tokens(x: Tensor, k: int, threshold: float, min_cluster_num: int,
+                           token_mask: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                           eps: float = 2e-6) -> Dict[str, Tensor]:
+    """Decision margins, computed in fp64 from the same fp32 inputs.  A decision whose margin is
+    below `eps` (fp32 rounding class for values of O(0.1..1)) may legitimately flip between two
+    correct fp32 implementations with different summation orders; parity tests demand bit-exact
+    integers everywhere else ("bit-exact indices are numerically fragile")."""
+    r = cluster_dpc_knn(x.double(), k, threshold, min_cluster_num, token_mask,
+                        None if noise is None else noise.double())
+    s = r.score.reshape(-1)
+    if not r.fallback:
+        centre_margin = (s - threshold).abs()
+    else:
+        srt = torch.sort(s, descending=True).values
+        kth, nxt = srt[min_cluster_num - 1], srt[min(min_cluster_num, s.numel() - 1)]
+        centre_margin = torch.minimum((s - kth).abs(), (s - nxt).abs())
+        centre_margin[torch.topk(s, min_cluster_num).indices[:-1]] = torch.maximum(
+            centre_margin[torch.topk(s, min_cluster_num).indices[:-1]], (kth - nxt).abs().expand(min_cluster_num - 1))
+    d = r.dist[r.index_down, :]
+    if d.shape[0] > 1:
+        two = torch.topk(d, 2, dim=0, largest=False).values
+        assign_margin = two[1] - two[0]
+    else:
+        assign_margin = torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
+    assign_margin[r.index_down] = float("inf")
+    return dict(index_down=r.index_down, idx_cluster=r.idx_cluster, score=s,
+                centre_margin=centre_margin, assign_margin=assign_margin,
+                centres_fragile=bool((centre_margin < eps).any()),
+                fragile=(assign_margin < eps))
+
+
+# ----------------------------------------------------------------------------------------------
+# a5 — Block / Attention / Mlp (module.py:29-100)
+# ----------------------------------------------------------------------------------------------
+def block_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, nheads: int, depth: int,
+                  eps: float = 1e-5) -> Tensor:
+    """`Block.forward` (module.py:95-100) on x of shape (n, C), eval mode (dropouts are identity):
+    `depth` attention sub-layers sharing ONE norm1 (:81,88), then ONE norm2 + Mlp (:98).
+    Attention: fused qkv Linear with bias (:56,63), scale d_h^-0.5 (:54), softmax (:67), proj (:58).
+    Mlp: fc1, exact-erf GELU (nn.GELU default), fc2 (:39-45)."""
+    n, C = x.shape
+    dh = C // nheads
+    g1, b1 = sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"]
+    for i in range(depth):
+        a = prefix + f"layers.{i}.1."
+        y = F.layer_norm(x, (C,), g1, b1, eps)
+        qkv = F.linear(y, sd[a + "qkv.weight"], sd[a + "qkv.bias"]).reshape(n, 3, nheads, dh).permute(1, 2, 0, 3)
+        q, kk, v = qkv[0], qkv[1], qkv[2]                                           # (H, n, dh)
+        att = torch.softmax((q @ kk.transpose(-2, -1)) * (dh ** -0.5), dim=-1)
+        o = (att @ v).transpose(0, 1).reshape(n, C)
+        x = x + F.linear(o, sd[a + "proj.weight"], sd[a + "proj.bias"])
+    y = F.layer_norm(x, (C,), sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], eps)
+    y = F.gelu(F.linear(y, sd[prefix + "mlp.fc1.weight"], sd[prefix + "mlp.fc1.bias"]))
+    return x + F.linear(y, sd[prefix + "mlp.fc2.weight"], sd[prefix + "mlp.fc2.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# a4 — group_encoding (tokenizer.py:123-155)
+# ----------------------------------------------------------------------------------------------
+def group_encoding(sd: Dict[str, Tensor], hc: HeadConfig, x: Tensor, labels: Tensor) -> Tensor:
+    """For each unique label (ascending, :141): inner_encoder on that cluster's member tokens alone
+    (:150), then the uniform mean over members (:151); stack (:153).  `centers` is unused (:123)."""
+    out = []
+    for lab in labels.unique():
+        m = labels == lab
+        out.append(block_forward(sd, "inner_encoder.", x[m], hc.nheads, hc.inner_cluster_layers).mean(dim=0))
+    return torch.stack(out, dim=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# a7 — SetokTokenizer.forward per image (tokenizer.py:157-182, repairs D1/D2 of SURVEY.md §0.2)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class HeadResult:
+    tokens: Tensor          # (L, token_feat_dim)
+    idx_cluster: Tensor     # (N,) int64
+    score: Tensor           # (1, N)
+    index_down: Tensor      # (L,) int64
+    x: Tensor               # (N, C) features + positional encoding
+    group: Tensor           # (L, C) after group_encoding
+    inter: Tensor           # (L, C) after inter_encoder
+
+
+def head_forward(sd: Dict[str, Tensor], hc: HeadConfig, feats: Tensor, k=None, threshold=None,
+                 token_mask: Optional[Tensor] = None, noise: Optional[Tensor] = None) -> HeadResult:
+    N, C = feats.shape
+    h = w = int(math.sqrt(N))                                                       # :164
+    x = feats + pos_encoding_2d(h, w, C, feats.dtype)                               # :165-168
+    _threshold = threshold if threshold else hc.threshold                          # :171 (truthiness)
+    _k = k if k else hc.min_cluster_num                                             # :172
+    cr = cluster_dpc_knn(x, _k, _threshold, hc.min_cluster_num, token_mask, noise)  # :174
+    group = group_encoding(sd, hc, x, cr.idx_cluster)                               # :177-178
+    inter = block_forward(sd, "inter_encoder.", group, hc.nheads, hc.intra_cluster_layers)  # :179 (+D2)
+    tokens = F.linear(inter, sd["out.weight"], sd["out.bias"])                      # :180
+    return HeadResult(tokens, cr.idx_cluster, cr.score, cr.index_down, x, group, inter)
+
+
+def encode(sd: Dict[str, Tensor], vc: VitConfig, hc: HeadConfig, images: Tensor, k=None, threshold=None,
+           noise: Optional[Tensor] = None) -> Tuple[Tensor, List[HeadResult]]:
+    """Tower on the batch, then the per-image head (the batch dimension is a loop — D1)."""
+    sd = normalise_tower_keys(sd)
+    feats = tower_forward(sd, vc, images, hc.mm_vision_select_layer, hc.mm_vision_select_feature)
+    res = [head_forward(sd, hc, feats[i], k, threshold, None, None if noise is None else noise[i])
+           for i in range(feats.shape[0])]
+    return feats, res
+
+
+# ----------------------------------------------------------------------------------------------
+# a8 — mm_in_projector (src/model/multimodal_projector/builder.py:33-64) + encode_images
+#      (src/model/setokim_arch.py:206-211)
+# ----------------------------------------------------------------------------------------------
+def projector_forward(psd: Dict[str, Tensor], projector_type: str, x: Tensor) -> Tensor:
+    """'linear' | 'mlp{N}x_gelu[_Norm]' | 'identity'.  Keys follow nn.Sequential numbering."""
+    import re
+    if projector_type == "identity":
+        return x
+    if projector_type == "linear":
+        return F.linear(x, psd["weight"], psd["bias"])
+    use_norm = "_Norm" in projector_type
+    m = re.match(r"^mlp(\d+)x_gelu$", projector_type.replace("_Norm", ""))
+    if not m:
+        raise ValueError(f"Unknown projector type: {projector_type}")
+    depth = int(m.group(1))
+    i = 0
+    x = F.linear(x, psd[f"{i}.weight"], psd[f"{i}.bias"]); i += 1
+    if use_norm:
+        x = F.layer_norm(x, (x.shape[-1],), psd[f"{i}.weight"], psd[f"{i}.bias"], 1e-5); i += 1
+    for _ in range(1, depth):
+        x = F.gelu(x); i += 1
+        x = F.linear(x, psd[f"{i}.weight"], psd[f"{i}.bias"]); i += 1
+    return x
+
+
+def encode_images(sd, psd, projector_type, vc: VitConfig, hc: HeadConfig, images: Tensor, k=None,
+                  threshold=None, noise=None) -> List[Tensor]:
+    """encode_images (setokim_arch.py:206-211) with the ragged result D3 requires: per image
+    (L_i, D) after mm_in_projector."""
+    _, res = encode(sd, vc, hc, images, k, threshold, noise)
+    return [projector_forward(psd, projector_type, r.tokens) for r in res]
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded synthetic weights (no pretrained weights / network exist: SURVEY.md §8d)
+# ----------------------------------------------------------------------------------------------
+def init_head_weights(hc: HeadConfig, seed: int = 1, dtype=torch.float32) -> Dict[str, Tensor]:
+    """xavier-uniform Linear weights, zero biases, unit LayerNorms (tokenizer.py:59-72) under
+    `torch.manual_seed(seed)`, with the reference's state-dict key names."""
+    g = torch.Generator().manual_seed(seed)
+    C, ff = hc.hidden_dim, hc.dim_feedforward
+
+    def xavier(o, i):
+        a = math.sqrt(6.0 / (i + o))
+        return (torch.rand(o, i, generator=g, dtype=torch.float32) * 2 - 1).mul_(a).to(dtype)
+
+    sd: Dict[str, Tensor] = {}
+    for name, depth in (("inner_encoder", hc.inner_cluster_layers), ("inter_encoder", hc.intra_cluster_layers)):
+        for nm in ("norm1", "norm2"):
+            sd[f"{name}.{nm}.weight"] = torch.ones(C, dtype=dtype)
+            sd[f"{name}.{nm}.bias"] = torch.zeros(C, dtype=dtype)
+        for i in range(depth):
+            sd[f"{name}.layers.{i}.1.qkv.weight"] = xavier(3 * C, C)
+            sd[f"{name}.layers.{i}.1.qkv.bias"] = torch.zeros(3 * C, dtype=dtype)
+            sd[f"{name}.layers.{i}.1.proj.weight"] = xavier(C, C)
+            sd[f"{name}.layers.{i}.1.proj.bias"] = torch.zeros(C, dtype=dtype)
+        sd[f"{name}.mlp.fc1.weight"] = xavier(ff, C)
+        sd[f"{name}.mlp.fc1.bias"] = torch.zeros(ff, dtype=dtype)
+        sd[f"{name}.mlp.fc2.weight"] = xavier(C, ff)
+        sd[f"{name}.mlp.fc2.bias"] = torch.zeros(C, dtype=dtype)
+    sd["out.weight"] = xavier(hc.token_feat_dim, C)
+    sd["out.bias"] = torch.zeros(hc.token_feat_dim, dtype=dtype)
+    return sd
+
+
+def init_tower_weights(vc: VitConfig, seed: int = 0, dtype=torch.float32, perturb: float = 0.02) -> Dict[str, Tensor]:
+    """Seeded random ViT weights with HF CLIPVisionModel key names (transformers 5.x spelling).
+    Standard deviations follow HF CLIP's published init (factor 1: q/k/v and fc2 at
+    C^-0.5 (2L)^-0.5, out_proj at C^-0.5, fc1 at (2C)^-0.5, patch/position embedding 0.02, class
+    embedding C^-0.5) so that token features keep a realistic spread through the depth (with it the
+    DPC-kNN scores of random images land around 0.1); biases and LayerNorm affine
+    parameters are additionally perturbed by `perturb` so that parity tests exercise them."""
+    g = torch.Generator().manual_seed(seed)
+    C, I, L, p = vc.hidden_size, vc.intermediate_size, vc.num_hidden_layers, TOWER_PREFIX
+    in_std = C ** -0.5 * (2 * L) ** -0.5
+    out_std = C ** -0.5
+    fc_std = (2 * C) ** -0.5
+
+    def rn(*shape, s):
+        return (torch.randn(*shape, generator=g, dtype=torch.float32) * s).to(dtype)
+
+    sd = {p + "embeddings.class_embedding": rn(C, s=C ** -0.5),
+          p + "embeddings.patch_embedding.weight": rn(C, vc.num_channels, vc.patch_size, vc.patch_size, s=0.02),
+          p + "embeddings.position_embedding.weight": rn(vc.num_patches + 1, C, s=0.02),
+          p + "pre_layrnorm.weight": 1 + rn(C, s=perturb), p + "pre_layrnorm.bias": rn(C, s=perturb),
+          p + "post_layernorm.weight": torch.ones(C, dtype=dtype), p + "post_layernorm.bias": torch.zeros(C, dtype=dtype)}
+    for i in range(L):
+        q = p + f"encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            sd[q + f"self_attn.{nm}.weight"] = rn(C, C, s=in_std)
+            sd[q + f"self_attn.{nm}.bias"] = rn(C, s=perturb)
+        sd[q + "self_attn.out_proj.weight"] = rn(C, C, s=out_std)
+        sd[q + "self_attn.out_proj.bias"] = rn(C, s=perturb)
+        for nm in ("layer_norm1", "layer_norm2"):
+            sd[q + nm + ".weight"] = 1 + rn(C, s=perturb)
+            sd[q + nm + ".bias"] = rn(C, s=perturb)
+        sd[q + "mlp.fc1.weight"] = rn(I, C, s=fc_std); sd[q + "mlp.fc1.bias"] = rn(I, s=perturb)
+        sd[q + "mlp.fc2.weight"] = rn(C, I, s=in_std); sd[q + "mlp.fc2.bias"] = rn(C, s=perturb)
+    return sd
+
+
+def planted_features(N: int, C: int, m: int, seed: int = 0, centre_std: float = 2.0,
+                     noise_std: float = 0.05) -> Tensor:
+    """Piecewise-constant feature map with m Voronoi regions on the sqrt(N) grid:
+    exercises the dynamic-k branch (score > threshold) at the default threshold."""
+    g = torch.Generator().manual_seed(seed)
+    h = int(math.sqrt(N))
+    sites = torch.rand(m, 2, generator=g) * h
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(h, dtype=torch.float32), indexing="ij")
+    pts = torch.stack([yy.reshape(-1), xx.reshape(-1)], dim=-1)
+    region = torch.cdist(pts, sites).argmin(dim=-1)
+    centres = torch.randn(m, C, generator=g) * centre_std
+    return centres[region] + torch.randn(N, C, generator=g) * noise_std

@@ -1,0 +1,197 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (RAC, oracle/rac_harness.py).
+
+Runs only in the build container (needs /root/reference).  The .npz files hold data only: inputs
+(or the seeds that regenerate them bit-exactly with torch's CPU generator), weights for the small
+cases, and the reference's outputs at every stage.  Usage:  python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import rac_harness as R          # noqa: E402
+import setok_oracle as O         # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def load_weights_into(tok, sd):
+    missing, unexpected = tok.load_state_dict(sd, strict=False)
+    bad = [m for m in missing if "layers." not in m or ".0." not in m.split("layers.")[1][:6]]
+    # `layers.{i}.0.*` are aliases of norm1 (module.py:87-88): fine if "missing"
+    assert not unexpected, unexpected
+    assert all(".0.weight" in m or ".0.bias" in m or m.endswith("inv_freq") for m in missing), missing
+
+
+def mid_threshold(tok, feats, rank, k=None, token_mask=None, noise=None):
+    """A threshold halfway between the rank-th and (rank+1)-th largest reference scores, so that
+    the dynamic-k branch yields L == rank with the widest possible decision margin."""
+    st = R.rac_head_single(tok, feats, k=k, threshold=1e9, token_mask=token_mask, noise=noise, return_stages=True)
+    s = torch.sort(st["score"].reshape(-1), descending=True).values
+    return float((s[rank - 1] + s[rank]) / 2)
+
+
+def small_tok(hidden=64, heads=4, layers=3, mlp=128, img=112, patch=14, ff=128, tfd=96, mcn=8, thr=0.5, sel=-2):
+    d = R.make_clip_dir(hidden, layers, heads, mlp, img, patch, seed=0)
+    return R.build_reference_tokenizer(d, hidden_dim=hidden, token_feat_dim=tfd, dim_feedforward=ff,
+                                       min_cluster_num=mcn, threshold=thr, select_layer=sel)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_head_small():
+    """Head (a2..a7) at small dims: all weights + inputs + every stage output."""
+    tok = small_tok()
+    sd = {k: v for k, v in tok.state_dict().items() if not k.startswith("image_feature_encoder")}
+    cfg = dict(hidden_dim=64, token_feat_dim=96, nheads=2, dim_feedforward=128, min_cluster_num=8, threshold=0.5)
+    g = torch.Generator().manual_seed(11)
+    cases = {}
+    N, C = 64, 64
+    feats_rand = torch.randn(N, C, generator=g)
+    noise = torch.rand(N, generator=g)
+    mask = (torch.rand(N, generator=g) > 0.25).float()
+    planted = O.planted_features(N, C, 5, seed=7)
+    thr_dyn = mid_threshold(tok, feats_rand, 13, noise=noise)
+    thr_msk = mid_threshold(tok, feats_rand, 9, token_mask=mask, noise=noise)
+    specs = {
+        "fallback":   dict(feats=feats_rand, k=None, threshold=None, token_mask=None, noise=noise),
+        "dynamic":    dict(feats=feats_rand, k=None, threshold=thr_dyn, token_mask=None, noise=noise),
+        "planted":    dict(feats=planted, k=6, threshold=None, token_mask=None, noise=None),
+        "masked":     dict(feats=feats_rand, k=None, threshold=thr_msk, token_mask=mask, noise=noise),
+        "k_explicit": dict(feats=feats_rand, k=3, threshold=0.9, token_mask=None, noise=None),
+        "n16_direct": dict(feats=torch.randn(16, C, generator=g), k=4, threshold=None, token_mask=None, noise=None),
+    }
+    out = {"cfg_keys": np.array(list(cfg.keys())), "cfg_vals": np.array(list(cfg.values()), dtype=np.float64)}
+    for k, v in sd.items():
+        out["w:" + k] = npy(v)
+    for name, s in specs.items():
+        st = R.rac_head_single(tok, s["feats"], k=s["k"], threshold=s["threshold"], token_mask=s["token_mask"],
+                               noise=s["noise"], return_stages=True)
+        print(f"  head_small/{name}: L={st['tokens'].shape[0]}")
+        out[f"{name}:feats"] = npy(s["feats"])
+        out[f"{name}:k"] = np.array(-1 if s["k"] is None else s["k"])
+        out[f"{name}:threshold"] = np.array(-1.0 if s["threshold"] is None else s["threshold"])
+        if s["token_mask"] is not None:
+            out[f"{name}:token_mask"] = npy(s["token_mask"])
+        if s["noise"] is not None:
+            out[f"{name}:noise"] = npy(s["noise"])
+        for key in ("x", "index_down", "idx_cluster", "score", "group", "inter", "tokens"):
+            out[f"{name}:{key}"] = npy(st[key])
+    save("head_small", **out)
+
+
+def gen_cluster_full():
+    """cluster_dpc_knn (a3) at the BASELINE dims (C=1024; N=256 and 576) on seeded planted feature
+    maps: only seeds + the reference's integer/score outputs are stored (inputs regenerate
+    bit-exactly from oracle.planted_features)."""
+    tok = small_tok(hidden=64)      # cluster_dpc_knn uses no weights; only min_cluster_num matters
+    out = {}
+    C = 1024
+    for N in (256, 576):
+        for m, k, thr, mcn in ((2, 8, 0.5, 64), (4, 8, 0.5, 64), (8, 8, 0.5, 64), (16, 8, 0.5, 64),
+                               (12, 64, 0.5, 64), (8, 8, 1e9, 32)):
+            tok.min_cluster_num = mcn
+            x = O.planted_features(N, C, m, seed=100 + m) + O.pos_encoding_2d(int(N ** .5), int(N ** .5), C)
+            with R.FixedNoise(None):
+                idx_down, idx_cluster, score = tok.cluster_dpc_knn(x, k, None, thr)
+            name = f"N{N}_m{m}_k{k}_mcn{mcn}_thr{thr:g}"
+            print(f"  cluster_full/{name}: L={idx_down.numel()}")
+            out[name + ":index_down"] = npy(idx_down).astype(np.int32)
+            out[name + ":idx_cluster"] = npy(idx_cluster).astype(np.int32)
+            out[name + ":score"] = npy(score)
+            out[name + ":spec"] = np.array([N, C, m, 100 + m, k, mcn, thr], dtype=np.float64)
+    save("cluster_full", **out)
+
+
+def gen_e2e_small():
+    """Tower + head end to end at small dims with all weights stored (ViT hidden 64, 3 layers,
+    4 heads, 112^2 / patch 14 -> N=64)."""
+    tok = small_tok(thr=0.5, mcn=8)
+    sd = O.normalise_tower_keys(dict(tok.state_dict()))
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(3, 3, 112, 112, generator=g)
+    noise = torch.rand(3, 64, generator=g)
+    out = {}
+    for k, v in sd.items():
+        if ".layers." in k and k.split(".")[0] in ("inner_encoder", "inter_encoder") and k.split(".")[3] == "0":
+            continue                      # aliases of norm1
+        out["w:" + k] = npy(v)
+    out["images"] = npy(images)
+    out["noise"] = npy(noise)
+    for sel in (-2, -1):
+        tok.image_feature_encoder.select_layer = sel
+        f0 = tok.image_feature_encoder(images)
+        for thr in (0.5, round(mid_threshold(tok, f0[0], 11, noise=noise[0]), 4)):
+            feats, res = R.rac_forward(tok, images, threshold=thr, noise=noise, return_stages=True)
+            tag = f"sel{sel}_{'fallback' if thr == 0.5 else 'dynamic'}"
+            out[f"{tag}:threshold"] = np.array(thr)
+            out[f"{tag}:feats"] = npy(feats)
+            for i, r in enumerate(res):
+                print(f"  e2e_small/{tag}/img{i}: L={r['tokens'].shape[0]}")
+                for key in ("index_down", "idx_cluster", "score", "tokens"):
+                    out[f"{tag}:{i}:{key}"] = npy(r[key])
+    save("e2e_small", **out)
+
+
+def gen_tower_features_vitl():
+    """Reference tower + head at the full ViT-L/14-224 dims (cfg2): weights from seeds
+    (oracle.init_tower_weights / init_head_weights), 2 images.  Stores the reference's tower
+    features in full (so clustering parity can start from IDENTICAL fp32 features)
+    and every downstream output."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    vc = O.VitConfig()                                   # ViT-L/14-224
+    hc = O.HeadConfig(threshold=0.125)                   # dyn-k fires with random-init features (§8d)
+    tsd = O.init_tower_weights(vc, seed=0)
+    hsd = O.init_head_weights(hc, seed=1)
+    d = R.make_clip_dir(vc.hidden_size, vc.num_hidden_layers, vc.num_attention_heads, vc.intermediate_size,
+                        vc.image_size, vc.patch_size, seed=0)
+    tok = R.build_reference_tokenizer(d, hidden_dim=1024, token_feat_dim=4096, dim_feedforward=4096,
+                                      min_cluster_num=64, threshold=0.125, select_layer=-2)
+    full = dict(tsd); full.update(hsd)
+    load_weights_into(tok, full)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(2, 3, 224, 224, generator=g)
+    out = {"spec": np.array([0, 1, 3], dtype=np.int64)}   # tower seed, head seed, image seed
+    feats, res = R.rac_forward(tok, images, noise=None, return_stages=True)
+    out["feats"] = npy(feats)
+    for i, r in enumerate(res):
+        print(f"  vitl/img{i}: L={r['tokens'].shape[0]} score[{r['score'].min():.4f},{r['score'].max():.4f}]")
+        out[f"{i}:index_down"] = npy(r["index_down"]).astype(np.int32)
+        out[f"{i}:idx_cluster"] = npy(r["idx_cluster"]).astype(np.int32)
+        out[f"{i}:score"] = npy(r["score"])
+        out[f"{i}:group"] = npy(r["group"]).astype(np.float32)
+        out[f"{i}:tokens"] = npy(r["tokens"]).astype(np.float32)
+    # fallback branch on the same features (default threshold 0.5 -> topk 64)
+    for i in range(2):
+        r = R.rac_head_single(tok, feats[i], threshold=0.5, return_stages=True)
+        out[f"{i}:fb:index_down"] = npy(r["index_down"]).astype(np.int32)
+        out[f"{i}:fb:idx_cluster"] = npy(r["idx_cluster"]).astype(np.int32)
+        out[f"{i}:fb:tokens_rowsum"] = npy(r["tokens"].double().sum(dim=1))
+    save("vitl_224", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl"]
+    if "head_small" in which:
+        gen_head_small()
+    if "cluster_full" in which:
+        gen_cluster_full()
+    if "e2e_small" in which:
+        gen_e2e_small()
+    if "vitl" in which:
+        gen_tower_features_vitl()

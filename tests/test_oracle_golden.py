@@ -1,0 +1,151 @@
+"""The oracle (oracle/setok_oracle.py) against the committed golden vectors, which are outputs of
+the REFERENCE itself (tests/golden/make_golden.py ran RAC in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import setok_oracle as O
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+HEAD_CASES = ["fallback", "dynamic", "planted", "masked", "k_explicit", "n16_direct"]
+
+
+@pytest.mark.parametrize("case", HEAD_CASES)
+def test_head_small_matches_reference(golden_dir, case):
+    z = _load(golden_dir, "head_small")
+    cfg = dict(zip([str(k) for k in z["cfg_keys"]], z["cfg_vals"]))
+    hc = O.HeadConfig(hidden_dim=int(cfg["hidden_dim"]), token_feat_dim=int(cfg["token_feat_dim"]),
+                      min_cluster_num=int(cfg["min_cluster_num"]), threshold=float(cfg["threshold"]),
+                      nheads=int(cfg["nheads"]), dim_feedforward=int(cfg["dim_feedforward"]))
+    sd = {k[2:]: _t(z[k]) for k in z.files if k.startswith("w:")}
+    k = int(z[f"{case}:k"]); thr = float(z[f"{case}:threshold"])
+    tm = _t(z[f"{case}:token_mask"]) if f"{case}:token_mask" in z.files else None
+    nz = _t(z[f"{case}:noise"]) if f"{case}:noise" in z.files else None
+    r = O.head_forward(sd, hc, _t(z[f"{case}:feats"]), k=None if k < 0 else k,
+                       threshold=None if thr < 0 else thr, token_mask=tm, noise=nz)
+    assert torch.equal(r.x, _t(z[f"{case}:x"]))                       # pos-enc add is bit-exact
+    assert torch.equal(r.index_down, _t(z[f"{case}:index_down"]))     # integers: bit-exact
+    assert torch.equal(r.idx_cluster, _t(z[f"{case}:idx_cluster"]))
+    assert r.idx_cluster.dtype == torch.int64 and tuple(r.score.shape) == (1, r.x.shape[0])
+    torch.testing.assert_close(r.score, _t(z[f"{case}:score"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(r.group, _t(z[f"{case}:group"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r.tokens, _t(z[f"{case}:tokens"]), rtol=1e-4, atol=1e-5)
+
+
+def test_cluster_full_dims_matches_reference(golden_dir):
+    z = _load(golden_dir, "cluster_full")
+    names = sorted({k.split(":")[0] for k in z.files})
+    assert len(names) == 12
+    for name in names:
+        N, C, m, seed, k, mcn, thr = z[name + ":spec"]
+        N, C, m, seed, k, mcn = int(N), int(C), int(m), int(seed), int(k), int(mcn)
+        h = int(N ** 0.5)
+        x = O.planted_features(N, C, m, seed=seed) + O.pos_encoding_2d(h, h, C)
+        r = O.cluster_dpc_knn(x, k, float(thr), mcn)
+        assert torch.equal(r.index_down, _t(z[name + ":index_down"]).long()), name
+        assert torch.equal(r.idx_cluster, _t(z[name + ":idx_cluster"]).long()), name
+        torch.testing.assert_close(r.score, _t(z[name + ":score"]), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["sel-2_fallback", "sel-2_dynamic", "sel-1_fallback", "sel-1_dynamic"])
+def test_e2e_small_matches_reference(golden_dir, tag):
+    z = _load(golden_dir, "e2e_small")
+    sd = {k[2:]: _t(z[k]) for k in z.files if k.startswith("w:")}
+    vc = O.VitConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                     image_size=112, patch_size=14)
+    sel = int(tag.split("_")[0][3:])
+    hc = O.HeadConfig(hidden_dim=64, token_feat_dim=96, min_cluster_num=8, threshold=0.5, nheads=2,
+                      dim_feedforward=128, mm_vision_select_layer=sel)
+    thr = float(z[f"{tag}:threshold"])
+    feats, res = O.encode(sd, vc, hc, _t(z["images"]), threshold=thr, noise=_t(z["noise"]))
+    # the tower is third-party arithmetic (HF sdpa vs restated eager softmax): fp32 rounding class
+    torch.testing.assert_close(feats, _t(z[f"{tag}:feats"]), rtol=1e-5, atol=5e-6)
+    for i, r in enumerate(res):
+        assert torch.equal(r.index_down, _t(z[f"{tag}:{i}:index_down"]))
+        assert torch.equal(r.idx_cluster, _t(z[f"{tag}:{i}:idx_cluster"]))
+        torch.testing.assert_close(r.tokens, _t(z[f"{tag}:{i}:tokens"]), rtol=1e-4, atol=2e-5)
+
+
+def test_vitl_head_from_reference_features(golden_dir):
+    """Full ViT-L dims: head on the reference's own tower features (identical fp32 input)."""
+    z = _load(golden_dir, "vitl_224")
+    hc = O.HeadConfig(threshold=0.125)
+    sd = O.init_head_weights(hc, seed=int(z["spec"][1]))
+    feats = _t(z["feats"])
+    for i in range(feats.shape[0]):
+        r = O.head_forward(sd, hc, feats[i])
+        assert torch.equal(r.index_down, _t(z[f"{i}:index_down"]).long())
+        assert torch.equal(r.idx_cluster, _t(z[f"{i}:idx_cluster"]).long())
+        torch.testing.assert_close(r.score, _t(z[f"{i}:score"]), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(r.group, _t(z[f"{i}:group"]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(r.tokens, _t(z[f"{i}:tokens"]), rtol=1e-4, atol=1e-5)
+        fb = O.head_forward(sd, hc, feats[i], threshold=0.5)
+        assert fb.index_down.numel() == 64
+        assert torch.equal(fb.index_down, _t(z[f"{i}:fb:index_down"]).long())
+        assert torch.equal(fb.idx_cluster, _t(z[f"{i}:fb:idx_cluster"]).long())
+        torch.testing.assert_close(fb.tokens.double().sum(dim=1), _t(z[f"{i}:fb:tokens_rowsum"]), rtol=1e-4, atol=1e-3)
+
+
+def test_vitl_tower_restatement_close_to_reference(golden_dir):
+    """Third-party boundary: restated CLIP ViT-L/14 vs the reference's HF tower (seeded weights)."""
+    z = _load(golden_dir, "vitl_224")
+    vc = O.VitConfig()
+    sd = O.init_tower_weights(vc, seed=int(z["spec"][0]))
+    g = torch.Generator().manual_seed(int(z["spec"][2]))
+    images = torch.randn(2, 3, 224, 224, generator=g)
+    feats = O.tower_forward(sd, vc, images[:1], -2)
+    torch.testing.assert_close(feats, _t(z["feats"])[:1], rtol=1e-4, atol=1e-4)
+
+
+def test_cluster_properties_and_quirks():
+    """Size-independent properties the reference's algorithm guarantees."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(100, 32, generator=g)
+    r = O.cluster_dpc_knn(x, 5, 1e9, 7)
+    assert r.fallback and r.index_down.numel() == 7
+    assert torch.equal(r.index_down, torch.sort(r.index_down).values)              # sorted fallback centres
+    assert torch.equal(r.idx_cluster[r.index_down], torch.arange(7))                # every centre owns itself
+    assert int(r.idx_cluster.min()) >= 0 and int(r.idx_cluster.max()) < 7
+    s = r.score.reshape(-1)
+    thr = float((s.max() + s.sort().values[-2]) / 2)
+    r2 = O.cluster_dpc_knn(x, 5, thr, 7)
+    assert not r2.fallback and r2.index_down.numel() == 1 and int(r2.idx_cluster.max()) == 0
+    # the highest-density token gets delta = min_j rowmax_j (the `[None, None]` broadcast quirk, :98-99)
+    top = int(r.density.argmax())
+    assert torch.isclose(r.delta[top], r.dist.max(dim=-1).values.min())
+
+
+def test_pos_encoding_layout():
+    pe = O.pos_encoding_2d(3, 4, 10)
+    assert tuple(pe.shape) == (12, 10)
+    ch = 6                                                                           # ceil(10/4)*2
+    inv = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+    row2 = torch.stack(((2 * inv).sin(), (2 * inv).cos()), -1).flatten()
+    col3 = torch.stack(((3 * inv).sin(), (3 * inv).cos()), -1).flatten()
+    assert torch.allclose(pe[2 * 4 + 3, :ch], row2) and torch.allclose(pe[2 * 4 + 3, ch:], col3[:4])
+
+
+def test_projector_types():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 8, generator=g)
+    psd = {"0.weight": torch.randn(6, 8, generator=g), "0.bias": torch.randn(6, generator=g),
+           "2.weight": torch.randn(6, 6, generator=g), "2.bias": torch.randn(6, generator=g)}
+    y = O.projector_forward(psd, "mlp2x_gelu", x)
+    ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(x, psd["0.weight"], psd["0.bias"])),
+                                     psd["2.weight"], psd["2.bias"])
+    assert torch.equal(y, ref)
+    assert O.projector_forward({}, "identity", x) is x
+    with pytest.raises(ValueError):
+        O.projector_forward({}, "bogus", x)

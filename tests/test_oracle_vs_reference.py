@@ -1,0 +1,79 @@
+"""Live pin of the oracle against the reference's own code (RAC).  Runs only where /root/reference
+exists (the build container); skipped on the GPU box."""
+import os
+
+import pytest
+import torch
+
+import rac_harness as R
+import setok_oracle as O
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not R.reference_available(), reason="/root/reference not present")]
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def tok():
+    d = R.make_clip_dir(64, 3, 4, 128, 112, 14, seed=0)
+    return R.build_reference_tokenizer(d, hidden_dim=64, token_feat_dim=96, dim_feedforward=128,
+                                       min_cluster_num=8, threshold=0.5)
+
+
+def _sd(tok):
+    return O.normalise_tower_keys(dict(tok.state_dict()))
+
+
+HC = O.HeadConfig(hidden_dim=64, token_feat_dim=96, min_cluster_num=8, threshold=0.5, nheads=2, dim_feedforward=128)
+VC = O.VitConfig(64, 128, 3, 4, 112, 14)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_head_bitwise_on_identical_features(tok, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(64, 64, generator=g)
+    noise = torch.rand(64, generator=g)
+    s0 = R.rac_head_single(tok, feats, threshold=1e9, noise=noise, return_stages=True)["score"].reshape(-1)
+    thr = float(s0.sort(descending=True).values[10:12].mean())
+    for kw in (dict(), dict(threshold=thr), dict(k=5, threshold=thr)):
+        ref = R.rac_head_single(tok, feats, noise=noise, return_stages=True, **kw)
+        got = O.head_forward(_sd(tok), HC, feats, noise=noise, **kw)
+        assert torch.equal(ref["x"], got.x)
+        assert torch.equal(ref["index_down"], got.index_down)
+        assert torch.equal(ref["idx_cluster"], got.idx_cluster)
+        assert torch.equal(ref["score"], got.score)            # same formula, same torch kernels
+        assert torch.equal(ref["tokens"], got.tokens)
+
+
+def test_cdist_restatement_is_bitwise(tok):
+    g = torch.Generator().manual_seed(9)
+    for n, c in ((26, 8), (256, 1024), (576, 256)):
+        x = torch.randn(n, c, generator=g)
+        assert torch.equal(torch.cdist(x, x), O.pairwise_dist(x))
+
+
+def test_tower_restatement_vs_hf(tok):
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(2, 3, 112, 112, generator=g)
+    for sel in (-2, -1, 1):
+        tok.image_feature_encoder.select_layer = sel
+        ref = tok.image_feature_encoder(images)
+        got = O.tower_forward(_sd(tok), VC, images, sel)
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=5e-6)
+    tok.image_feature_encoder.select_layer = -2
+
+
+def test_pos_encoding_bitwise(tok):
+    _, mod = R.load_reference()
+    for h, w, c in ((16, 16, 1024), (24, 24, 1024), (14, 14, 768), (3, 5, 10)):
+        pe = mod.PositionalEncoding2D(c)(torch.zeros(1, h, w, c))
+        assert torch.equal(pe.reshape(h * w, c), O.pos_encoding_2d(h, w, c))
+
+
+def test_reference_defects_still_present(tok):
+    """D1/D2 of SURVEY.md §0.2 — documents why RAC needs its two repairs."""
+    with pytest.raises(Exception):
+        tok(torch.randn(2, 3, 112, 112))
+    with pytest.raises(ValueError):
+        tok.inter_encoder(torch.randn(5, 64))
