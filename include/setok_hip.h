@@ -1,0 +1,135 @@
+/*
+ * setok_hip.h — C ABI of libsetok_hip.so, the MI355X (gfx950) implementation of the SeTok
+ * `encode_images` hot path.
+ *
+ * The reference (ChocoWu/SeTok) has NO native / FFI interface for this path: it is 100 % Python
+ * over stock torch ops.  The boundary a maintainer binds is therefore the
+ * set of torch-op groups of the reference's hot path; each entry point below cites the reference
+ * lines (relative to /root/reference/) whose arithmetic it replaces.  The Python host that mirrors
+ * the reference's `SetokTokenizer` / `build_vision_tower` / `encode_images` surface
+ * (setok_amd/) calls these through ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates
+ *     nothing, and synchronises nothing — outputs and workspaces are caller-allocated;
+ *   - `dtype` selects the activation/weight element type: SETOK_F32 (parity mode; fp32 MFMA,
+ *     exact fma chains) or SETOK_BF16 (throughput mode; bf16 MFMA, fp32 accumulation);
+ *     biases, LayerNorm affine parameters, scores and distances are always fp32;
+ *   - matrices are row-major and dense unless a leading dimension is given;
+ *   - return value: 0 on success, a negative SETOK_E* code otherwise; setok_last_error() returns
+ *     a thread-local human-readable message for the last failure.
+ */
+#ifndef SETOK_HIP_H
+#define SETOK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SETOK_ABI_VERSION 1
+
+enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
+enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
+enum { SETOK_OK = 0, SETOK_EINVAL = -1, SETOK_ELAUNCH = -2, SETOK_EUNSUPPORTED = -3 };
+
+int setok_abi_version(void);
+const char* setok_last_error(void);
+/* Name of the device the library sees ("" if none), its CU count; both cheap, host-side only. */
+int setok_device_info(char* name_host, int name_cap, int* cu_count_host);
+
+/* ---- dense layers ------------------------------------------------------------------------ */
+
+/* C[M,N] = act(A[M,K] · W[N,K]^T + bias[N]) + residual[M,N]          (bias, residual optional)
+ * Replaces every nn.Linear on the path: module.py:40,43 (Mlp), :63,71 (Attention qkv/proj),
+ * tokenizer.py:180 (`out`), multimodal_projector/builder.py:37-59 (mm_in_projector) and the HF CLIP
+ * q/k/v/out_proj/fc1/fc2 linears reached from clip_encoder.py:59.  `act` fuses nn.GELU (exact erf,
+ * module.py:41) or CLIP's quick_gelu.  A and W have element type `dtype`; C and residual have
+ * `out_dtype` (C may alias residual).  lda/ldc are row strides in elements; K % 64 == 0 (bf16) or
+ * K % 16 == 0 (fp32).  `batch` > 1 runs independent problems with the given element strides
+ * (bias shared). */
+int setok_linear(void* stream, int dtype, int out_dtype, const void* A, int64_t lda, const void* W,
+                 const float* bias, const void* residual, void* C, int64_t ldc, int M, int N, int K,
+                 int act, int batch, int64_t strideA, int64_t strideW, int64_t strideC);
+
+/* y[r,:] = LayerNorm(x[r,:]) * gamma + beta   — nn.LayerNorm (module.py:81,83; HF CLIP
+ * pre_layrnorm / layer_norm1 / layer_norm2).  Statistics in fp32.  x may alias y. */
+int setok_layernorm(void* stream, int dtype, const void* x, const float* gamma, const float* beta,
+                    void* y, int rows, int C, float eps);
+
+/* y = act(x) elementwise (n elements) — nn.GELU placed after a LayerNorm in the `mlp{N}x_gelu_Norm`
+ * projector (multimodal_projector/builder.py:48-58), where it cannot be fused into a GEMM epilogue. */
+int setok_activation(void* stream, int dtype, const void* x, void* y, int64_t n, int act);
+
+/* Block-diagonal ("varlen") multi-head self-attention over contiguous row segments.
+ * qkv: (rows, 3*H*Dh) laid out [q | k | v], heads inside — the layout both the fused `qkv` Linear
+ * of module.py:63 and a concatenated HF q/k/v projection produce.  Row r attends to the rows of
+ * its own segment [seg_offsets[s], seg_offsets[s+1]) only:
+ *   - ViT tower: segments = images (T rows each)                       clip_encoder.py:59 (HF eager attention)
+ *   - inner_encoder: segments = clusters (member tokens only)          tokenizer.py:147-150, module.py:61-73
+ *   - inter_encoder: segments = images (L_i cluster tokens each)       tokenizer.py:179
+ * out: (rows, H*Dh) = softmax(q k^T * scale) v, heads concatenated (module.py:70).
+ * seg_offsets: int32[n_segs+1] on the device; if NULL, uniform segments of `seg_len` rows. */
+int setok_attention(void* stream, int dtype, const void* qkv, const int32_t* seg_offsets, int n_segs,
+                    int seg_len, void* out, int rows, int H, int Dh, float scale);
+
+/* ---- ViT tower glue (HF CLIPVisionEmbeddings reached from clip_encoder.py:59) ------------ */
+
+/* im2col for the stride-p patch conv: images (B,3,H,W) -> patches (B*g*g, Kpad) with column index
+ * c*p*p + py*p + px (the flattening of conv weight (C,3,p,p)); columns >= 3*p*p are zero. */
+int setok_patchify(void* stream, int dtype, const void* images, void* patches, int B, int H, int W,
+                   int p, int Kpad);
+/* tokens[b,0,:] = cls + pos[0]; tokens[b,1+i,:] = patch_embed[b,i,:] + pos[1+i]  (embeddings.forward) */
+int setok_vit_assemble(void* stream, int dtype, const void* patch_embed, const void* cls, const void* pos,
+                       void* tokens, int B, int N, int C);
+
+/* ---- SeTok head glue --------------------------------------------------------------------- */
+
+/* x[b,i,:] = hidden[b, i+skip, :] + pos2d[i,:] : feature_select's `[:, 1:]` (clip_encoder.py:43,
+ * skip = 1 for 'patch', 0 for 'cls_patch') fused with the PositionalEncoding2D add
+ * (tokenizer.py:164-168).  hidden: (B, N+skip, C); pos2d: (N, C) in `dtype`; the sum is rounded
+ * once to `dtype`, as the reference's `x + pos_emb` is. */
+int setok_select_add_pos(void* stream, int dtype, const void* hidden, const void* pos2d, void* x,
+                         int B, int N, int C, int skip);
+
+/* cluster_dpc_knn (tokenizer.py:78-121), batched over B images, each exactly as the reference's
+ * per-image call:  D = cdist(x,x)/sqrt(C) (:82) [token_mask :84-86]; density from the k nearest
+ * (self included) (:88-90) + noise*1e-6 (:91) [* token_mask :93-94]; delta with the row-j-max
+ * quirk (:96-99); score = delta*density (:101); centres = {score > threshold} (:103) else the
+ * min_cluster_num best scores, ascending by index (:104-107); idx_cluster = argmin over centre
+ * rows, centres own themselves (:111-119).
+ *   x:          (B, N, C) `dtype`                      noise, token_mask: (B, N) fp32 or NULL
+ *   idx_cluster:(B, N) int64 out                       score: (B, N) fp32 out  (reference: (1,N) per image)
+ *   index_down: (B, N) int64 out, first counts[b] entries valid, rest -1
+ *   counts:     (B) int32 out  = L_b
+ *   dist_ws:    (B, N, N) fp32 workspace (the scaled distance matrix; stays in L2/MALL at these sizes)
+ *   vec_ws:     (B, 4, N) fp32 workspace (density, row max, delta, spare)
+ * Requires N <= 1024, 1 <= k <= N, min_cluster_num <= N. */
+int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int B, int N, int C, int k,
+                          float threshold, int min_cluster_num, const float* noise,
+                          const float* token_mask, int64_t* idx_cluster, float* score,
+                          int64_t* index_down, int32_t* counts, float* dist_ws, float* vec_ws);
+
+/* Stable counting sort of each image's tokens by cluster id (`labels.unique()` order ==
+ * ascending label, tokenizer.py:141-143) plus the segment tables the ragged stages need:
+ *   perm:        (B*N) int32  — sorted position -> source row (b*N + i)
+ *   seg_offsets: (total+1) int32, total = sum_b counts[b]: cluster segments in sorted-row space
+ *   img_offsets: (B+1) int32 — prefix sum of counts (segments of the inter-encoder / ragged output)
+ * Capacity of seg_offsets must be B*N+1. */
+int setok_cluster_sort(void* stream, const int64_t* idx_cluster, const int32_t* counts, int B, int N,
+                       int32_t* perm, int32_t* seg_offsets, int32_t* img_offsets);
+
+/* out[p,:] = x[perm[p],:]   (the `x[m]` gathers of tokenizer.py:150, all clusters at once) */
+int setok_gather_rows(void* stream, int dtype, const void* x, const int32_t* perm, void* out, int rows, int C);
+
+/* out[s,:] = mean over rows [seg_offsets[s], seg_offsets[s+1]) of h   (tokenizer.py:151).
+ * n_segs_dev: device int32 holding the segment count (= img_offsets[B]); max_segs = launch bound. */
+int setok_segment_mean(void* stream, int dtype, const void* h, const int32_t* seg_offsets,
+                       const int32_t* n_segs_dev, int max_segs, void* out, int C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SETOK_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libsetok_hip.so (C ABI: include/setok_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this raises — the product path never
+routes through the CPU oracle or plain torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsetok_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes; mirrors include/setok_hip.h declaration by declaration
+SIGNATURES = {
+    "setok_abi_version": [],
+    "setok_last_error": [],
+    "setok_device_info": [C.c_char_p, _i, C.POINTER(_i)],
+    "setok_linear": [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i64, _i64, _i64],
+    "setok_layernorm": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f],
+    "setok_activation": [_vp, _i, _vp, _vp, _i64, _i],
+    "setok_attention": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f],
+    "setok_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
+    "setok_vit_assemble": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "setok_select_add_pos": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i],
+    "setok_cluster_dpc_knn": [_vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "setok_cluster_sort": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "setok_gather_rows": [_vp, _i, _vp, _vp, _vp, _i, _i],
+    "setok_segment_mean": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i],
+}
+
+_lib = None
+
+
+class SetokHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SetokHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C setok_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "setok_last_error" else _i
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise SetokHipError(f"{name} failed (code {rc}): {lib.setok_last_error().decode()}")
+
+
+def device_info():
+    lib = load()
+    buf = C.create_string_buffer(256)
+    cu = _i(0)
+    rc = lib.setok_device_info(buf, 256, C.byref(cu))
+    if rc != 0:
+        raise SetokHipError(lib.setok_last_error().decode())
+    return buf.value.decode(), cu.value

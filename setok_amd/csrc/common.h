@@ -1,0 +1,96 @@
+// common.h — shared device/host helpers for libsetok_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/setok_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+
+// ---- error reporting (host) -----------------------------------------------------------------
+char* setok_err_buf();                      // thread-local, defined in capi.hip
+int setok_fail(int code, const char* fmt, ...);
+
+#define SETOK_CHECK_ARG(cond, ...) \
+    do { if (!(cond)) return setok_fail(SETOK_EINVAL, __VA_ARGS__); } while (0)
+
+#define SETOK_CHECK_LAUNCH(what)                                                              \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess) return setok_fail(SETOK_ELAUNCH, "%s: %s", what, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- element access templated on the storage type ------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;                       // elements per 16-byte access
+    __device__ static inline float ld(const float* p) { return *p; }
+    __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16> {
+    static constexpr int VEC = 8;
+    __device__ static inline float ld(const bf16* p) { return (float)*p; }
+    __device__ static inline void st(bf16* p, float v) { *p = (bf16)v; }
+};
+
+// 16-byte vector load/store of VEC elements as floats
+template <typename T> __device__ inline void ld_vec(const T* p, float* out);
+template <> __device__ inline void ld_vec<float>(const float* p, float* out) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+template <> __device__ inline void ld_vec<bf16>(const bf16* p, float* out) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+template <typename T> __device__ inline void st_vec(T* p, const float* in);
+template <> __device__ inline void st_vec<float>(float* p, const float* in) {
+    f32x4 v = {in[0], in[1], in[2], in[3]};
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ inline void st_vec<bf16>(bf16* p, const float* in) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)in[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+
+// ---- wave-level reductions (64 lanes) -------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ inline float act_apply(float v, int act) {
+    if (act == SETOK_ACT_QUICK_GELU) return v / (1.0f + expf(-1.702f * v));
+    if (act == SETOK_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}

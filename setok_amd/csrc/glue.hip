@@ -1,0 +1,188 @@
+// glue.hip — bandwidth-bound layout kernels around the GEMMs: patch extraction, token assembly,
+// feature_select + positional add, row gather, segmented mean.  All use 16-byte accesses.
+#include "common.h"
+
+// images (B,3,H,W) -> patches (B*g*g, Kpad), column = c*p*p + py*p + px, zero padded to Kpad.
+template <typename T>
+__global__ void patchify_kernel(const T* __restrict__ img, T* __restrict__ out, int B, int H, int W, int p, int Kpad) {
+    const int gh = H / p, gw = W / p, K = 3 * p * p;
+    const int64_t total = (int64_t)B * gh * gw * Kpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % Kpad);
+        const int64_t pr = i / Kpad;
+        float v = 0.f;
+        if (col < K) {
+            const int px = col % p, py = (col / p) % p, c = col / (p * p);
+            const int gx = (int)(pr % gw), gy = (int)((pr / gw) % gh), b = (int)(pr / ((int64_t)gw * gh));
+            v = Elem<T>::ld(img + (((int64_t)b * 3 + c) * H + gy * p + py) * W + gx * p + px);
+        }
+        Elem<T>::st(out + i, v);
+    }
+}
+
+extern "C" int setok_patchify(void* stream, int dtype, const void* images, void* patches, int B, int H, int W, int p, int Kpad) {
+    SETOK_CHECK_ARG(images && patches, "setok_patchify: null operand");
+    SETOK_CHECK_ARG(B > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= 3 * p * p, "setok_patchify: bad shape");
+    const int64_t total = (int64_t)B * (H / p) * (W / p) * Kpad;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) patchify_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)images, (bf16*)patches, B, H, W, p, Kpad);
+    else if (dtype == SETOK_F32) patchify_kernel<float><<<grid, 256, 0, s>>>((const float*)images, (float*)patches, B, H, W, p, Kpad);
+    else return setok_fail(SETOK_EINVAL, "setok_patchify: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_patchify");
+    return SETOK_OK;
+}
+
+// tokens[b,0] = cls + pos[0]; tokens[b,1+i] = pe[b,i] + pos[1+i]
+template <typename T>
+__global__ void vit_assemble_kernel(const T* __restrict__ pe, const T* __restrict__ cls, const T* __restrict__ pos,
+                                    T* __restrict__ tok, int B, int N, int C) {
+    constexpr int V = Elem<T>::VEC;
+    const int cv = C / V;
+    const int64_t total = (int64_t)B * (N + 1) * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t r = i / cv;
+        const int t = (int)(r % (N + 1)), b = (int)(r / (N + 1));
+        float a[V], q[V];
+        if (t == 0) ld_vec<T>(cls + c, a); else ld_vec<T>(pe + ((int64_t)b * N + t - 1) * C + c, a);
+        ld_vec<T>(pos + (int64_t)t * C + c, q);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] += q[j];
+        st_vec<T>(tok + r * C + c, a);
+    }
+}
+
+extern "C" int setok_vit_assemble(void* stream, int dtype, const void* patch_embed, const void* cls, const void* pos,
+                                  void* tokens, int B, int N, int C) {
+    SETOK_CHECK_ARG(patch_embed && cls && pos && tokens, "setok_vit_assemble: null operand");
+    SETOK_CHECK_ARG(B > 0 && N > 0 && C % 8 == 0, "setok_vit_assemble: bad shape");
+    const int64_t total = (int64_t)B * (N + 1) * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) vit_assemble_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)patch_embed, (const bf16*)cls, (const bf16*)pos, (bf16*)tokens, B, N, C);
+    else if (dtype == SETOK_F32) vit_assemble_kernel<float><<<grid, 256, 0, s>>>((const float*)patch_embed, (const float*)cls, (const float*)pos, (float*)tokens, B, N, C);
+    else return setok_fail(SETOK_EINVAL, "setok_vit_assemble: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_vit_assemble");
+    return SETOK_OK;
+}
+
+// x[b,i] = hidden[b, i+skip] + pos2d[i]
+template <typename T>
+__global__ void select_add_pos_kernel(const T* __restrict__ hid, const T* __restrict__ pos, T* __restrict__ x,
+                                      int B, int N, int C, int skip) {
+    constexpr int V = Elem<T>::VEC;
+    const int cv = C / V;
+    const int64_t total = (int64_t)B * N * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t r = i / cv;
+        const int t = (int)(r % N), b = (int)(r / N);
+        float a[V], q[V];
+        ld_vec<T>(hid + ((int64_t)b * (N + skip) + t + skip) * C + c, a);
+        ld_vec<T>(pos + (int64_t)t * C + c, q);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] += q[j];
+        st_vec<T>(x + r * C + c, a);
+    }
+}
+
+extern "C" int setok_select_add_pos(void* stream, int dtype, const void* hidden, const void* pos2d, void* x,
+                                    int B, int N, int C, int skip) {
+    SETOK_CHECK_ARG(hidden && pos2d && x, "setok_select_add_pos: null operand");
+    SETOK_CHECK_ARG(B > 0 && N > 0 && C % 8 == 0 && (skip == 0 || skip == 1), "setok_select_add_pos: bad shape");
+    const int64_t total = (int64_t)B * N * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) select_add_pos_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)hidden, (const bf16*)pos2d, (bf16*)x, B, N, C, skip);
+    else if (dtype == SETOK_F32) select_add_pos_kernel<float><<<grid, 256, 0, s>>>((const float*)hidden, (const float*)pos2d, (float*)x, B, N, C, skip);
+    else return setok_fail(SETOK_EINVAL, "setok_select_add_pos: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_select_add_pos");
+    return SETOK_OK;
+}
+
+// out[p] = x[perm[p]]
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ x, const int32_t* __restrict__ perm, T* __restrict__ out, int rows, int C) {
+    constexpr int V = Elem<T>::VEC;
+    const int cv = C / V;
+    const int64_t total = (int64_t)rows * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t r = i / cv;
+        float a[V];
+        ld_vec<T>(x + (int64_t)perm[r] * C + c, a);
+        st_vec<T>(out + r * C + c, a);
+    }
+}
+
+extern "C" int setok_gather_rows(void* stream, int dtype, const void* x, const int32_t* perm, void* out, int rows, int C) {
+    SETOK_CHECK_ARG(x && perm && out, "setok_gather_rows: null operand");
+    SETOK_CHECK_ARG(rows >= 0 && C % 8 == 0, "setok_gather_rows: bad shape");
+    if (rows == 0) return SETOK_OK;
+    const int64_t total = (int64_t)rows * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) gather_rows_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, perm, (bf16*)out, rows, C);
+    else if (dtype == SETOK_F32) gather_rows_kernel<float><<<grid, 256, 0, s>>>((const float*)x, perm, (float*)out, rows, C);
+    else return setok_fail(SETOK_EINVAL, "setok_gather_rows: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_gather_rows");
+    return SETOK_OK;
+}
+
+// out[s] = mean_{r in [off[s], off[s+1])} h[r]      one block per segment, fp32 accumulation in row order
+template <typename T>
+__global__ void segment_mean_kernel(const T* __restrict__ h, const int32_t* __restrict__ off, const int32_t* __restrict__ n_segs,
+                                    T* __restrict__ out, int C) {
+    constexpr int V = Elem<T>::VEC;
+    const int s = blockIdx.x;
+    if (s >= *n_segs) return;
+    const int r0 = off[s], r1 = off[s + 1];
+    const float n = (float)(r1 - r0);
+    for (int c = threadIdx.x * V; c < C; c += blockDim.x * V) {
+        float acc[V], a[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            ld_vec<T>(h + (int64_t)r * C + c, a);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] /= n;
+        st_vec<T>(out + (int64_t)s * C + c, acc);
+    }
+}
+
+extern "C" int setok_segment_mean(void* stream, int dtype, const void* h, const int32_t* seg_offsets,
+                                  const int32_t* n_segs_dev, int max_segs, void* out, int C) {
+    SETOK_CHECK_ARG(h && seg_offsets && n_segs_dev && out, "setok_segment_mean: null operand");
+    SETOK_CHECK_ARG(max_segs >= 0 && C % 8 == 0, "setok_segment_mean: bad shape");
+    if (max_segs == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = C / 8 >= 256 ? 256 : (C / 8 >= 128 ? 128 : 64);
+    if (dtype == SETOK_BF16) segment_mean_kernel<bf16><<<max_segs, threads, 0, s>>>((const bf16*)h, seg_offsets, n_segs_dev, (bf16*)out, C);
+    else if (dtype == SETOK_F32) segment_mean_kernel<float><<<max_segs, threads, 0, s>>>((const float*)h, seg_offsets, n_segs_dev, (float*)out, C);
+    else return setok_fail(SETOK_EINVAL, "setok_segment_mean: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_segment_mean");
+    return SETOK_OK;
+}
+
+template <typename T>
+__global__ void activation_kernel(const T* x, T* y, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<T>::st(y + i, act_apply(Elem<T>::ld(x + i), act));
+}
+
+extern "C" int setok_activation(void* stream, int dtype, const void* x, void* y, int64_t n, int act) {
+    SETOK_CHECK_ARG(x && y && n >= 0, "setok_activation: bad operand");
+    SETOK_CHECK_ARG(act >= SETOK_ACT_NONE && act <= SETOK_ACT_GELU_ERF, "setok_activation: bad act %d", act);
+    if (n == 0) return SETOK_OK;
+    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) activation_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, (bf16*)y, n, act);
+    else if (dtype == SETOK_F32) activation_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, n, act);
+    else return setok_fail(SETOK_EINVAL, "setok_activation: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_activation");
+    return SETOK_OK;
+}

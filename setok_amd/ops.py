@@ -1,0 +1,169 @@
+"""Torch-tensor front end of the C ABI: pointer extraction, shape/dtype checks, output allocation.
+
+PyTorch is plumbing here (device memory + streams); every operator below is one call into
+libsetok_hip.so on torch's current HIP stream."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, BF16, F32  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+def _code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"setok_amd supports float32 and bfloat16, got {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
+    return t.data_ptr()
+
+
+def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is not None:
+        assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()
+    return t
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def k_align(dt: torch.dtype) -> int:
+    return 64 if dt == torch.bfloat16 else 16
+
+
+def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+           act: int = ACT_NONE, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """out = act(a @ w.T + bias) + residual;  a: (M, K), w: (N, K), bias fp32 (N,)."""
+    M, K = a.shape
+    N, K2 = w.shape
+    assert K == K2 and a.dtype == w.dtype
+    od = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=od, device=a.device)
+    assert out.shape == (M, N) and out.dtype == od
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.dtype == od
+    _lib.call("setok_linear", _stream(), _code(a.dtype), _code(od), _p(a), K, _p(w), _p(_f32(bias)), _p(residual),
+              _p(out), N, M, N, K, act, 1, 0, 0, 0)
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("setok_layernorm", _stream(), _code(x.dtype), _p(x), _p(_f32(gamma)), _p(_f32(beta)), _p(out), rows, Cc, eps)
+    return out
+
+
+def attention(qkv: Tensor, H: int, Dh: int, scale: float, seg_len: int, seg_offsets: Optional[Tensor] = None,
+              n_segs: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """Block-diagonal attention.  Uniform segments of `seg_len` rows, or ragged ones given by the int32
+    device tensor `seg_offsets` (n_segs + 1 entries; `seg_len` is then an upper bound on the length)."""
+    rows = qkv.shape[0]
+    assert qkv.shape[1] == 3 * H * Dh
+    if out is None:
+        out = torch.empty((rows, H * Dh), dtype=qkv.dtype, device=qkv.device)
+    if seg_offsets is not None:
+        assert seg_offsets.dtype == torch.int32 and seg_offsets.numel() >= n_segs + 1
+    _lib.call("setok_attention", _stream(), _code(qkv.dtype), _p(qkv), _p(seg_offsets), n_segs, seg_len, _p(out),
+              rows, H, Dh, scale)
+    return out
+
+
+def patchify(images: Tensor, p: int, kpad: int) -> Tensor:
+    B, Cin, H, W = images.shape
+    assert Cin == 3
+    out = torch.empty((B * (H // p) * (W // p), kpad), dtype=images.dtype, device=images.device)
+    _lib.call("setok_patchify", _stream(), _code(images.dtype), _p(images), _p(out), B, H, W, p, kpad)
+    return out
+
+
+def vit_assemble(patch_embed: Tensor, cls: Tensor, pos: Tensor, B: int, N: int) -> Tensor:
+    Cc = patch_embed.shape[1]
+    out = torch.empty((B * (N + 1), Cc), dtype=patch_embed.dtype, device=patch_embed.device)
+    _lib.call("setok_vit_assemble", _stream(), _code(patch_embed.dtype), _p(patch_embed), _p(cls), _p(pos), _p(out), B, N, Cc)
+    return out
+
+
+def select_add_pos(hidden: Tensor, pos2d: Tensor, B: int, N: int, skip: int) -> Tensor:
+    Cc = hidden.shape[-1]
+    assert hidden.numel() == B * (N + skip) * Cc and pos2d.shape == (N, Cc) and pos2d.dtype == hidden.dtype
+    out = torch.empty((B * N, Cc), dtype=hidden.dtype, device=hidden.device)
+    _lib.call("setok_select_add_pos", _stream(), _code(hidden.dtype), _p(hidden), _p(pos2d), _p(out), B, N, Cc, skip)
+    return out
+
+
+def cluster_dpc_knn(x: Tensor, B: int, N: int, k: int, threshold: float, min_cluster_num: int,
+                    noise: Optional[Tensor] = None, token_mask: Optional[Tensor] = None
+                    ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """x: (B*N, C).  Returns (idx_cluster int64 (B,N), score fp32 (B,N), index_down int64 (B,N) [-1 padded],
+    counts int32 (B,)).  No host synchronisation."""
+    Cc = x.shape[-1]
+    assert x.numel() == B * N * Cc
+    dev = x.device
+    idx = torch.empty((B, N), dtype=torch.int64, device=dev)
+    score = torch.empty((B, N), dtype=torch.float32, device=dev)
+    index_down = torch.empty((B, N), dtype=torch.int64, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    dist_ws = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    vec_ws = torch.empty((B, 4, N), dtype=torch.float32, device=dev)
+    if noise is not None:
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        assert noise.numel() == B * N
+    if token_mask is not None:
+        token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
+        assert token_mask.numel() == B * N
+    _lib.call("setok_cluster_dpc_knn", _stream(), _code(x.dtype), _p(x), B, N, Cc, int(k), float(threshold),
+              int(min_cluster_num), _p(noise), _p(token_mask), _p(idx), _p(score), _p(index_down), _p(counts),
+              _p(dist_ws), _p(vec_ws))
+    return idx, score, index_down, counts
+
+
+def cluster_sort(idx_cluster: Tensor, counts: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    B, N = idx_cluster.shape
+    dev = idx_cluster.device
+    perm = torch.empty((B * N,), dtype=torch.int32, device=dev)
+    seg_offsets = torch.empty((B * N + 1,), dtype=torch.int32, device=dev)
+    img_offsets = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    _lib.call("setok_cluster_sort", _stream(), _p(idx_cluster), _p(counts), B, N, _p(perm), _p(seg_offsets), _p(img_offsets))
+    return perm, seg_offsets, img_offsets
+
+
+def gather_rows(x: Tensor, perm: Tensor) -> Tensor:
+    rows, Cc = perm.numel(), x.shape[-1]
+    out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    _lib.call("setok_gather_rows", _stream(), _code(x.dtype), _p(x), _p(perm), _p(out), rows, Cc)
+    return out
+
+
+def segment_mean(h: Tensor, seg_offsets: Tensor, n_segs_dev: Tensor, n_segs: int) -> Tensor:
+    """n_segs_dev: 1-element int32 device tensor (e.g. img_offsets[B:]); n_segs: rows to allocate/launch."""
+    Cc = h.shape[-1]
+    out = torch.empty((n_segs, Cc), dtype=h.dtype, device=h.device)
+    _lib.call("setok_segment_mean", _stream(), _code(h.dtype), _p(h), _p(seg_offsets), _p(n_segs_dev), n_segs, _p(out), Cc)
+    return out
+
+
+def activation(x: Tensor, act: int, out: Optional[Tensor] = None) -> Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("setok_activation", _stream(), _code(x.dtype), _p(x), _p(out), x.numel(), act)
+    return out

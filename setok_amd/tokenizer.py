@@ -1,0 +1,375 @@
+"""SetokTokenizer — MI355X-native counterpart of the reference's SeTok encoder
+(src/model/setok/tokenizer.py:13-182), the object LLaVA-derived code calls the "vision tower".
+
+Same constructor kwargs (tokenizer.py:14-34), same state-dict key names
+(`inner_encoder.norm1.*`, `inner_encoder.layers.{i}.1.{qkv,proj}.*`, `inner_encoder.mlp.{fc1,fc2}.*`,
+`inter_encoder.*`, `out.*`, `image_feature_encoder.vision_tower.*`), same call signature
+`tower(images, k=None, threshold=None, token_mask=None) -> (image_features, idx_cluster, score)`.
+
+The arithmetic is the reference's (DPC-kNN clustering, per-cluster Block encoder + uniform mean,
+inter-cluster Block encoder, `out` Linear), executed for the whole batch at once on the HIP library:
+the reference's per-image Python loop and its per-cluster Python loop
+(tokenizer.py:147-152) become block-diagonal attention over cluster-sorted rows, so every Linear
+runs as one GEMM over all B*N tokens.  The per-image token count L_i varies (dynamic-k), hence the
+ragged return type.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .clip_encoder import CLIPVisionTower
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers with the reference's module tree (module.py:29-146)
+# ----------------------------------------------------------------------------------------------
+class Mlp(nn.Module):                                   # module.py:29-45
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise ValueError("only nn.GELU (exact erf) is implemented on the HIP path")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+
+class Attention(nn.Module):                             # module.py:48-73
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    """module.py:76-100: `depth` attention sub-layers sharing ONE norm1, then ONE norm2 + Mlp.
+    Eval-mode semantics (dropouts are identity; drop_path must be 0)."""
+
+    def __init__(self, dim, num_heads, mlp_hidden_dim, qkv_bias=True, qk_scale=None, proj_drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm, depth=0):
+        super().__init__()
+        if norm_layer is not nn.LayerNorm:
+            raise ValueError("only nn.LayerNorm is implemented on the HIP path")
+        if drop_path > 0.0:
+            raise ValueError("drop_path > 0 is a training-time regulariser; the HIP path is eval-only")
+        self.dim, self.num_heads = dim, num_heads
+        self.norm1 = norm_layer(dim)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.layers = nn.ModuleList()
+        for _ in range(depth):                           # same tree => same keys `layers.{i}.{0,1}.*`
+            self.layers.append(nn.Sequential(self.norm1,
+                                             Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale),
+                                             self.drop_path))
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=proj_drop)
+        self._packed: Dict[str, Any] = {}
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def _pack(self):
+        w = self.mlp.fc1.weight
+        key = (w.dtype, str(w.device), w._version)
+        if self._packed.get("key") == key:
+            return self._packed
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        self._packed = dict(
+            key=key, n1=(f32(self.norm1.weight), f32(self.norm1.bias)), n2=(f32(self.norm2.weight), f32(self.norm2.bias)),
+            attn=[dict(wqkv=l[1].qkv.weight.detach().contiguous(), bqkv=f32(l[1].qkv.bias),
+                       wproj=l[1].proj.weight.detach().contiguous(), bproj=f32(l[1].proj.bias), scale=l[1].scale)
+                  for l in self.layers],
+            w1=self.mlp.fc1.weight.detach().contiguous(), b1=f32(self.mlp.fc1.bias),
+            w2=self.mlp.fc2.weight.detach().contiguous(), b2=f32(self.mlp.fc2.bias), eps=self.norm1.eps)
+        return self._packed
+
+    @torch.no_grad()
+    def forward_rows(self, h: torch.Tensor, seg_offsets: torch.Tensor, n_segs: int, seg_len_bound: int) -> torch.Tensor:
+        """Block.forward (module.py:95-100) on packed rows `h` (rows, C), each row attending only within
+        its own segment.  `h` is updated in place and returned."""
+        pk = self._pack()
+        H, Dh = self.num_heads, self.dim // self.num_heads
+        y = None
+        for a in pk["attn"]:
+            y = ops.layernorm(h, *pk["n1"], pk["eps"], out=y)
+            qkv = ops.linear(y, a["wqkv"], a["bqkv"])
+            o = ops.attention(qkv, H, Dh, a["scale"], seg_len=seg_len_bound, seg_offsets=seg_offsets, n_segs=n_segs)
+            ops.linear(o, a["wproj"], a["bproj"], residual=h, out=h)
+        y = ops.layernorm(h, *pk["n2"], pk["eps"], out=y)
+        u = ops.linear(y, pk["w1"], pk["b1"], act=ops.ACT_GELU_ERF)
+        ops.linear(u, pk["w2"], pk["b2"], residual=h, out=h)
+        return h
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, n, C) -> (B, n, C), the reference's call shape."""
+        B, n, C = x.shape
+        h = x.reshape(B * n, C).contiguous().clone()
+        offs = torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device=x.device)
+        return self.forward_rows(h, offs, B, n).reshape(B, n, C)
+
+
+class PositionalEncoding2D(nn.Module):
+    """module.py:105-146 — the table is built once per (h, w, C, dtype) on the host exactly as the
+    reference computes it (fp32 sin/cos, cast to the feature dtype) and cached on the device."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.org_channels = channels
+        channels = int(np.ceil(channels / 4) * 2)
+        self.channels = channels
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, channels, 2).float() / channels))
+        self.register_buffer("inv_freq", inv_freq)
+        self._cache: Dict[Any, torch.Tensor] = {}
+
+    def table(self, h: int, w: int, dtype: torch.dtype, device) -> torch.Tensor:
+        key = (h, w, dtype, str(device))
+        if key not in self._cache:
+            inv = self.inv_freq.detach().float().cpu()
+
+            def emb1d(n):
+                s = torch.einsum("i,j->ij", torch.arange(n, dtype=inv.dtype), inv)
+                return torch.stack((s.sin(), s.cos()), dim=-1).flatten(-2, -1)
+            emb = torch.zeros((h, w, self.channels * 2), dtype=dtype)
+            emb[:, :, : self.channels] = emb1d(h).unsqueeze(1).to(dtype)
+            emb[:, :, self.channels: 2 * self.channels] = emb1d(w).to(dtype)
+            self._cache[key] = emb[:, :, : self.org_channels].reshape(h * w, self.org_channels).contiguous().to(device)
+        return self._cache[key]
+
+    def forward(self, tensor):
+        if len(tensor.shape) != 4:
+            raise RuntimeError("The input tensor has to be 4d!")            # module.py:123-124
+        b, h, w, c = tensor.shape
+        return self.table(h, w, tensor.dtype, tensor.device).reshape(1, h, w, c).repeat(b, 1, 1, 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# ragged result
+# ----------------------------------------------------------------------------------------------
+class RaggedTokens:
+    """Per-image variable-length token sets: `packed` (sum L_i, D) on the device + host-side offsets.
+    Supports what the reference's callers do with `image_features` (setokim_arch.py:265-293,
+    pairDataset.py:419-447): `feats[i]` -> (L_i, D), `len(feats)`, iteration, `.shape` of an item."""
+
+    def __init__(self, packed: torch.Tensor, counts: Sequence[int]):
+        self.packed = packed
+        self.counts = [int(c) for c in counts]
+        self.offsets = np.concatenate([[0], np.cumsum(self.counts)]).astype(np.int64)
+        assert int(self.offsets[-1]) == packed.shape[0]
+
+    def __len__(self):
+        return len(self.counts)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            idx = range(*i.indices(len(self)))
+            return [self[j] for j in idx]
+        if i < 0:
+            i += len(self)
+        return self.packed[int(self.offsets[i]): int(self.offsets[i + 1])]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def dim(self):
+        return self.packed.dim()
+
+    @property
+    def dtype(self):
+        return self.packed.dtype
+
+    @property
+    def device(self):
+        return self.packed.device
+
+    def map(self, fn) -> "RaggedTokens":
+        """Apply a row-wise operator (e.g. mm_in_projector) to all tokens at once."""
+        return RaggedTokens(fn(self.packed), self.counts)
+
+    def to_padded(self, pad_value: float = 0.0):
+        B, Lmax, D = len(self), max(self.counts) if self.counts else 0, self.packed.shape[-1]
+        out = self.packed.new_full((B, Lmax, D), pad_value)
+        mask = torch.zeros((B, Lmax), dtype=torch.bool, device=self.packed.device)
+        for i in range(B):
+            out[i, : self.counts[i]] = self[i]
+            mask[i, : self.counts[i]] = True
+        return out, mask
+
+    def tolist(self) -> List[torch.Tensor]:
+        return list(self)
+
+
+# ----------------------------------------------------------------------------------------------
+class SetokTokenizer(nn.Module):
+    def __init__(self,
+                 vision_tower: Any = "google/siglip-so400m-patch14-384",
+                 unfreeze_mm_vision_tower: Optional[bool] = False,
+                 mm_vision_select_feature: Optional[str] = "patch",
+                 mm_vision_select_layer: Optional[int] = -2,
+                 delay_load: Optional[bool] = False,
+                 hidden_dim: Optional[int] = 4096,
+                 token_feat_dim: Optional[int] = 4096,
+                 min_cluster_num: Optional[int] = 64,
+                 threshold: Optional[float] = 0.5,
+                 nheads: Optional[int] = 2,
+                 dim_feedforward: Optional[int] = 4096,
+                 proj_drop: Optional[float] = 0.2,
+                 drop_path: Optional[float] = 0.0,
+                 inner_cluster_layers: Optional[int] = 2,
+                 intra_cluster_layers: Optional[int] = 2,
+                 attn_drop: Optional[float] = 0.0,
+                 act_layer: nn.Module = nn.GELU,
+                 norm_layer: nn.Module = nn.LayerNorm,
+                 **kwargs) -> None:
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.token_feat_dim = token_feat_dim
+        self.inner_encoder = Block(hidden_dim, nheads, dim_feedforward, proj_drop=proj_drop, attn_drop=attn_drop,
+                                   drop_path=drop_path, act_layer=act_layer, norm_layer=norm_layer, depth=inner_cluster_layers)
+        self.inter_encoder = Block(hidden_dim, nheads, dim_feedforward, proj_drop=proj_drop, attn_drop=attn_drop,
+                                   drop_path=drop_path, act_layer=act_layer, norm_layer=norm_layer, depth=intra_cluster_layers)
+        self.position_embedding = PositionalEncoding2D(hidden_dim)
+        self.out = nn.Linear(hidden_dim, token_feat_dim)
+        self.min_cluster_num = min_cluster_num
+        self.threshold = threshold
+        self.initialize_weights()
+        self.image_feature_encoder = CLIPVisionTower(vision_tower,
+                                                     unfreeze_mm_vision_tower=unfreeze_mm_vision_tower,
+                                                     mm_vision_select_feature=mm_vision_select_feature,
+                                                     mm_vision_select_layer=mm_vision_select_layer,
+                                                     delay_load=delay_load)
+        self.image_processor = self.image_feature_encoder.image_processor
+        if self.image_feature_encoder.is_loaded and self.image_feature_encoder.hidden_size != hidden_dim:
+            # there is no projection between the tower and Block(hidden_dim)
+            raise ValueError(f"hidden_dim ({hidden_dim}) must equal the vision tower hidden size "
+                             f"({self.image_feature_encoder.hidden_size})")
+
+    # tokenizer.py:59-72
+    def initialize_weights(self):
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1.0)
+
+    # -- attributes LLaVA-style callers use -----------------------------------------
+    @property
+    def dtype(self):                                     # tokenizer.py:75-76 refers to a non-existent attribute (D4)
+        return self.out.weight.dtype
+
+    @property
+    def device(self):
+        return self.out.weight.device
+
+    @property
+    def is_loaded(self):
+        return self.image_feature_encoder.is_loaded
+
+    def load_model(self, device_map=None):
+        self.image_feature_encoder.load_model(device_map=device_map)
+        self.image_processor = self.image_feature_encoder.image_processor
+
+    @property
+    def config(self):
+        return self.image_feature_encoder.config
+
+    @property
+    def hidden_size(self):
+        return self.token_feat_dim
+
+    @property
+    def num_patches(self):
+        return self.image_feature_encoder.num_patches
+
+    @property
+    def num_patches_per_side(self):
+        return self.image_feature_encoder.num_patches_per_side
+
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.token_feat_dim, device=self.device, dtype=self.dtype)
+
+    # -- stages ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def cluster_dpc_knn(self, x, k, token_mask=None, threshold=0.53, noise=None):
+        """tokenizer.py:78-121 for ONE image: x (N, C) -> (index_down (L,), idx_cluster (N,), score (1, N))."""
+        N = x.shape[0]
+        idx, score, index_down, counts = ops.cluster_dpc_knn(x.contiguous(), 1, N, k, threshold, self.min_cluster_num,
+                                                             noise, token_mask)
+        L = int(counts[0])
+        return index_down[0, :L], idx[0], score
+
+    @torch.no_grad()
+    def encode_features(self, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, token_mask=None,
+                        noise=None, return_stages: bool = False):
+        """tokenizer.py:162-180 for a batch, from the tower's hidden rows (B*(N+skip), C)."""
+        tower = self.image_feature_encoder
+        if tower.select_feature == "patch":
+            skip = 1
+        elif tower.select_feature == "cls_patch":
+            skip = 0
+        else:
+            raise ValueError(f"Unexpected select feature: {tower.select_feature}")
+        C = hidden_rows.shape[-1]
+        N = hidden_rows.shape[0] // B - skip
+        h = w = int(math.sqrt(N))                                                  # tokenizer.py:164
+        if h * w != N:
+            raise ValueError(f"{N} tokens do not form a square grid (einops rearrange would fail, tokenizer.py:165)")
+        pos = self.position_embedding.table(h, w, hidden_rows.dtype, hidden_rows.device)
+        x = ops.select_add_pos(hidden_rows, pos, B, N, skip)                       # :165-168
+        _threshold = threshold if threshold else self.threshold                    # :171
+        _k = k if k else self.min_cluster_num                                      # :172
+        idx, score, index_down, counts = ops.cluster_dpc_knn(x, B, N, _k, _threshold, self.min_cluster_num,
+                                                             noise, token_mask)    # :174
+        perm, seg_offsets, img_offsets = ops.cluster_sort(idx, counts)
+        counts_h = counts.cpu().tolist()                                           # the one host sync: L_i sizes the ragged output
+        total = int(sum(counts_h))
+        hs = ops.gather_rows(x, perm)                                              # x[m] for every cluster (:150)
+        hs = self.inner_encoder.forward_rows(hs, seg_offsets, total, N)            # :150
+        group = ops.segment_mean(hs, seg_offsets, img_offsets[B:], total)          # :151-153
+        stages = dict(x=x, group=group.clone()) if return_stages else None
+        inter = self.inter_encoder.forward_rows(group, img_offsets, B, max(counts_h))   # :179 (+D2)
+        tokens = ops.linear(inter, self.out.weight.detach().contiguous(), self.out.bias.detach().float().contiguous())  # :180
+        out = (RaggedTokens(tokens, counts_h), idx, score.reshape(B, 1, N))
+        if return_stages:
+            stages.update(index_down=index_down, counts=counts_h, inter=inter)
+            return out + (stages,)
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, k=None, threshold=None, token_mask=None, noise=None):
+        """images (B, 3, H, W) or a list of (3, H, W) tensors ->
+        (image_features: RaggedTokens with B items (L_i, token_feat_dim), idx_cluster (B, N) int64,
+         score (B, 1, N)).  `noise` (B, N) replaces the reference's implicit `torch.rand` density
+        tie-break (tokenizer.py:91); None == no noise."""
+        if isinstance(x, (list, tuple)):
+            x = torch.stack([im for im in x], dim=0)
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        B = x.shape[0]
+        hidden = self.image_feature_encoder.hidden_rows(x)                         # tokenizer.py:161
+        if hidden.dtype != self.dtype:
+            hidden = hidden.to(self.dtype)
+        return self.encode_features(hidden, B, k, threshold, token_mask, noise)
+
+    @torch.no_grad()
+    def encode(self, image: torch.Tensor, **kw) -> torch.Tensor:
+        """Dataset-side contract (pairDataset.py:419-421): one image -> tokens (L, D); L = num_tokens."""
+        feats, _, _ = self.forward(image if image.dim() == 4 else image.unsqueeze(0), **kw)
+        return feats[0]

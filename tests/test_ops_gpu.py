@@ -1,0 +1,273 @@
+"""Per-operator parity of the HIP library (through the C ABI) against the CPU oracle / plain torch
+fp32 restatements of the same op.  Needs a real MI355X: `pytest -m gpu`."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import setok_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from setok_amd import ops
+
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------------------------------------
+# setok_linear
+# ---------------------------------------------------------------------------------------------
+LIN_SHAPES = [(128, 128, 64), (257, 192, 128), (1, 96, 64), (300, 1024, 1024), (514, 3072, 1024), (77, 64, 640)]
+
+
+@pytest.mark.parametrize("M,N,K", LIN_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_f32(M, N, K, act):
+    a, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3), _rand(M, N, seed=4)
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = [ref, O.quick_gelu(ref), F.gelu(ref)][act] + r.double()
+    got = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV), act=act)
+    assert _rel_err(got, ref) < 2e-6              # exact-f32 MFMA: fp32 rounding class only
+
+
+@pytest.mark.parametrize("M,N,K", LIN_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_bf16(M, N, K, act):
+    a, w = _rand(M, K, seed=1).bfloat16(), (_rand(N, K, seed=2, scale=K ** -0.5)).bfloat16()
+    b, r = _rand(N, seed=3), _rand(M, N, seed=4).bfloat16()
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = [ref, O.quick_gelu(ref), F.gelu(ref)][act] + r.double()
+    got = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV), act=act)
+    assert got.dtype == torch.bfloat16
+    assert _rel_err(got, ref) < 6e-3              # one bf16 rounding of the result (2^-8) + fp32 accumulation
+    got32 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), r.float().to(DEV), act=act, out_dtype=torch.float32)
+    assert _rel_err(got32, ref) < 2e-5            # bf16 products are exact in fp32; only the accumulation order differs
+
+
+def test_linear_transpose_detecting():
+    """A = I with an asymmetric W catches a swapped C/D fragment mapping (cdna guide rule 16)."""
+    K = 128
+    w = torch.arange(K * K, dtype=torch.float32).reshape(K, K) / (K * K)
+    for dt, tol in ((torch.float32, 1e-7), (torch.bfloat16, 4e-3)):
+        got = ops.linear(torch.eye(K).to(dt).to(DEV), w.to(dt).to(DEV))
+        assert _rel_err(got, w.to(dt).double().t()) < tol
+
+
+# ---------------------------------------------------------------------------------------------
+# layernorm / attention
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("rows,C", [(5, 64), (1028, 1024), (33, 768)])
+def test_layernorm(dt, tol, rows, C):
+    x = (_rand(rows, C, seed=5) * 3 + 0.5).to(dt)
+    g, b = 1 + 0.1 * _rand(C, seed=6), 0.1 * _rand(C, seed=7)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)
+    got = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5)
+    assert _rel_err(got, ref) < tol
+
+
+def _attn_ref(qkv, H, Dh, scale, offsets):
+    qkv = qkv.double()
+    out = torch.zeros(qkv.shape[0], H * Dh, dtype=torch.float64)
+    for s0, s1 in zip(offsets[:-1], offsets[1:]):
+        blk = qkv[s0:s1].reshape(s1 - s0, 3, H, Dh).permute(1, 2, 0, 3)
+        att = torch.softmax(blk[0] @ blk[1].transpose(-1, -2) * scale, dim=-1)
+        out[s0:s1] = (att @ blk[2]).transpose(0, 1).reshape(s1 - s0, H * Dh)
+    return out
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("T,H,Dh,nimg", [(17, 4, 16, 3), (257, 16, 64, 2), (65, 2, 512, 2), (197, 12, 64, 1)])
+def test_attention_uniform(dt, tol, T, H, Dh, nimg):
+    qkv = _rand(nimg * T, 3 * H * Dh, seed=8).to(dt)
+    ref = _attn_ref(qkv, H, Dh, Dh ** -0.5, [i * T for i in range(nimg + 1)])
+    got = ops.attention(qkv.to(DEV), H, Dh, Dh ** -0.5, seg_len=T)
+    assert _rel_err(got, ref) < tol
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
+def test_attention_ragged(dt, tol):
+    H, Dh = 2, 32
+    lens = [1, 7, 64, 3, 1, 129, 20]
+    offs = np.concatenate([[0], np.cumsum(lens)]).tolist()
+    qkv = _rand(offs[-1], 3 * H * Dh, seed=9).to(dt)
+    ref = _attn_ref(qkv, H, Dh, Dh ** -0.5, offs)
+    so = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    got = ops.attention(qkv.to(DEV), H, Dh, Dh ** -0.5, seg_len=max(lens), seg_offsets=so, n_segs=len(lens))
+    assert _rel_err(got, ref) < tol
+
+
+# ---------------------------------------------------------------------------------------------
+# glue
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patchify_matches_conv(dt):
+    B, p, g = 2, 14, 4
+    img = _rand(B, 3, p * g, p * g, seed=10).to(dt)
+    w = _rand(8, 3, p, p, seed=11).to(dt)
+    kpad = ops.round_up(3 * p * p, 64)
+    pat = ops.patchify(img.to(DEV), p, kpad).cpu()
+    assert pat.shape == (B * g * g, kpad) and float(pat[:, 3 * p * p:].abs().max()) == 0.0
+    ref = F.conv2d(img.double(), w.double(), stride=p).flatten(2).transpose(1, 2).reshape(B * g * g, 8)
+    got = pat[:, :3 * p * p].double() @ w.double().reshape(8, -1).t()
+    assert _rel_err(got, ref) < 1e-12
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_assemble_and_select(dt):
+    B, N, C = 3, 16, 64
+    pe, cls, pos = _rand(B * N, C, seed=12).to(dt), _rand(C, seed=13).to(dt), _rand(N + 1, C, seed=14).to(dt)
+    tok = ops.vit_assemble(pe.to(DEV), cls.to(DEV), pos.to(DEV), B, N).cpu().reshape(B, N + 1, C)
+    ref = (torch.cat([cls.float().expand(B, 1, C), pe.float().reshape(B, N, C)], 1) + pos.float()[None]).to(dt)
+    assert torch.equal(tok, ref)
+    p2 = O.pos_encoding_2d(4, 4, C, dt)
+    for skip in (1, 0):
+        hid = _rand(B, N + skip, C, seed=15).to(dt)
+        x = ops.select_add_pos(hid.to(DEV), p2.to(DEV), B, N, skip).cpu().reshape(B, N, C)
+        assert torch.equal(x, (hid[:, skip:].float() + p2.float()[None]).to(dt))
+
+
+# ---------------------------------------------------------------------------------------------
+# clustering against the reference's golden vectors (integers bit-exact)
+# ---------------------------------------------------------------------------------------------
+def _score_ok(score_gpu, score_ref32, x, k, thr, mcn, noise=None, token_mask=None):
+    """score is a float by-product (the integers are the contract).  d^2 = |a|^2 + |b|^2 - 2 a.b cancels
+    catastrophically for near-duplicate tokens, so two correct fp32 implementations differ by far more
+    than 1 ulp there; judge both against the same algorithm in fp64: the GPU must be as close to the
+    exact answer as the reference's own fp32 run (x8 slack: with |x|^2 ~ 4600 one ulp of n_i + n_j is
+    already 1e-4 of a d^2 ~ 5), or within 2e-5 relative."""
+    r64 = O.cluster_dpc_knn(x.double(), k, thr, mcn, token_mask, None if noise is None else noise.double()).score.reshape(-1)
+    e_gpu = (score_gpu.reshape(-1).double() - r64).abs()
+    e_ref = (score_ref32.reshape(-1).double() - r64).abs()
+    bound = torch.maximum(8 * e_ref.max().expand_as(e_ref), 2e-5 * r64.abs() + 1e-7)
+    ok = bool((e_gpu <= bound).all())
+    if not ok:
+        i = int((e_gpu - bound).argmax())
+        print(f"score check: worst token {i}: gpu err {float(e_gpu[i]):.3e} (rel {float(e_gpu[i] / r64[i]):.3e}) bound {float(bound[i]):.3e} "
+              f"ref32 err max {float(e_ref.max()):.3e}; gpu err max {float(e_gpu.max()):.3e} rel max {float((e_gpu / r64.abs()).max()):.3e}")
+    return ok
+
+
+def _cluster_gpu(x, k, thr, mcn, noise=None, token_mask=None):
+    N = x.shape[0]
+    idx, score, index_down, counts = ops.cluster_dpc_knn(
+        x.to(DEV), 1, N, k, thr, mcn,
+        None if noise is None else noise.reshape(1, N), None if token_mask is None else token_mask.reshape(1, N))
+    L = int(counts[0])
+    return idx[0].cpu(), score.cpu(), index_down[0, :L].cpu(), L, index_down[0, L:].cpu()
+
+
+def test_cluster_head_small_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "head_small.npz"))
+    for case in ("fallback", "dynamic", "planted", "masked", "k_explicit"):
+        x = torch.from_numpy(z[f"{case}:x"])
+        k = int(z[f"{case}:k"]); thr = float(z[f"{case}:threshold"])
+        k = 8 if k < 0 else k
+        thr = 0.5 if thr < 0 else thr
+        nz = torch.from_numpy(z[f"{case}:noise"]) if f"{case}:noise" in z.files else None
+        tm = torch.from_numpy(z[f"{case}:token_mask"]) if f"{case}:token_mask" in z.files else None
+        idx, score, centres, L, pad = _cluster_gpu(x, k, thr, 8, nz, tm)
+        assert torch.equal(centres, torch.from_numpy(z[f"{case}:index_down"])), case
+        assert torch.equal(idx, torch.from_numpy(z[f"{case}:idx_cluster"])), case
+        assert bool((pad == -1).all())
+        assert _score_ok(score, torch.from_numpy(z[f"{case}:score"]), x, k, thr, 8, nz, tm), case
+
+
+def test_cluster_full_dims_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "cluster_full.npz"))
+    for name in sorted({k.split(":")[0] for k in z.files}):
+        N, C, m, seed, k, mcn, thr = z[name + ":spec"]
+        N, C, m, seed, k, mcn = int(N), int(C), int(m), int(seed), int(k), int(mcn)
+        h = int(N ** 0.5)
+        x = O.planted_features(N, C, m, seed=seed) + O.pos_encoding_2d(h, h, C)
+        idx, score, centres, L, _ = _cluster_gpu(x, k, float(thr), mcn)
+        assert torch.equal(centres, torch.from_numpy(z[name + ":index_down"]).long()), name
+        assert torch.equal(idx, torch.from_numpy(z[name + ":idx_cluster"]).long()), name
+        assert _score_ok(score, torch.from_numpy(z[name + ":score"]), x, k, float(thr), mcn), name
+
+
+def test_cluster_vitl_reference_features(golden_dir):
+    """Dynamic-k on the reference's own ViT-L tower features; bit-exact wherever the decision margin
+    (fp64 analysis of the same inputs) exceeds fp32 rounding."""
+    z = np.load(os.path.join(golden_dir, "vitl_224.npz"))
+    feats = torch.from_numpy(z["feats"])
+    x = feats + O.pos_encoding_2d(16, 16, 1024)[None]
+    idx, score, index_down, counts = ops.cluster_dpc_knn(x.to(DEV).reshape(-1, 1024), 2, 256, 64, 0.125, 64)
+    for i in range(2):
+        L = int(counts[i])
+        fr = O.cluster_fragile_tokens(x[i], 64, 0.125, 64)
+        ref_c = torch.from_numpy(z[f"{i}:index_down"]).long()
+        ref_i = torch.from_numpy(z[f"{i}:idx_cluster"]).long()
+        if not fr["centres_fragile"]:
+            assert L == ref_c.numel() and torch.equal(index_down[i, :L].cpu(), ref_c)
+            ok = (idx[i].cpu() == ref_i) | fr["fragile"]
+            assert bool(ok.all()), f"image {i}: {int((~ok).sum())} non-fragile tokens differ"
+        assert _score_ok(score[i].cpu(), torch.from_numpy(z[f"{i}:score"]), x[i], 64, 0.125, 64)
+    # fallback branch (threshold 0.5 -> 64 best scores)
+    idx, score, index_down, counts = ops.cluster_dpc_knn(x.to(DEV).reshape(-1, 1024), 2, 256, 64, 0.5, 64)
+    for i in range(2):
+        assert int(counts[i]) == 64
+        assert torch.equal(index_down[i, :64].cpu(), torch.from_numpy(z[f"{i}:fb:index_down"]).long())
+        assert torch.equal(idx[i].cpu(), torch.from_numpy(z[f"{i}:fb:idx_cluster"]).long())
+
+
+def test_cluster_batched_equals_per_image_and_bf16_runs():
+    B, N, C = 5, 256, 1024
+    xs = torch.stack([O.planted_features(N, C, 3 + i, seed=50 + i) for i in range(B)])
+    idx, score, index_down, counts = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, 8, 0.5, 64)
+    for i in range(B):
+        r = O.cluster_dpc_knn(xs[i], 8, 0.5, 64)
+        assert int(counts[i]) == r.index_down.numel()
+        assert torch.equal(idx[i].cpu(), r.idx_cluster)
+    # bf16 inputs: same algorithm on the bf16-rounded features (exact products, fp32 accumulate)
+    xb = xs.bfloat16()
+    idx_b, _, _, counts_b = ops.cluster_dpc_knn(xb.to(DEV).reshape(-1, C), B, N, 8, 0.5, 64)
+    for i in range(B):
+        r = O.cluster_dpc_knn(xb[i].float(), 8, 0.5, 64)
+        assert int(counts_b[i]) == r.index_down.numel()
+        assert torch.equal(idx_b[i].cpu(), r.idx_cluster)
+
+
+# ---------------------------------------------------------------------------------------------
+# sort / gather / segment mean
+# ---------------------------------------------------------------------------------------------
+def test_sort_gather_segment_mean():
+    B, N, C = 4, 64, 64
+    g = torch.Generator().manual_seed(20)
+    Ls = [1, 5, 64, 17]
+    idx = torch.stack([torch.cat([torch.arange(L), torch.randint(0, L, (N - L,), generator=g)])[torch.randperm(N, generator=g)]
+                       for L in Ls])
+    counts = torch.tensor(Ls, dtype=torch.int32)
+    perm, seg, img = ops.cluster_sort(idx.to(DEV), counts.to(DEV))
+    total = sum(Ls)
+    assert img.cpu().tolist() == np.concatenate([[0], np.cumsum(Ls)]).tolist()
+    perm, seg = perm.cpu().long(), seg.cpu()[:total + 1].long()
+    exp_perm, exp_seg = [], []
+    for b in range(B):
+        order = torch.sort(idx[b], stable=True).indices
+        exp_perm.append(order + b * N)
+        sizes = torch.bincount(idx[b], minlength=Ls[b])
+        exp_seg.append(b * N + torch.cumsum(sizes, 0) - sizes)
+    assert torch.equal(perm, torch.cat(exp_perm))
+    assert torch.equal(seg, torch.cat(exp_seg + [torch.tensor([B * N])]))
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 8e-3)):
+        x = _rand(B * N, C, seed=21).to(dt)
+        xs = ops.gather_rows(x.to(DEV), perm.int().to(DEV))
+        assert torch.equal(xs.cpu(), x[perm])
+        mean = ops.segment_mean(xs, seg.int().to(DEV), img.to(DEV)[B:], total).cpu()
+        ref = torch.stack([x[perm][seg[s]:seg[s + 1]].double().mean(0) for s in range(total)])
+        assert _rel_err(mean, ref) < tol
