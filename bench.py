@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py — SeTok encode_images throughput on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path — encode_images = ViT-L/14 tower -> +2-D pos -> DPC-kNN dynamic
+clustering -> per-cluster encoder + mean -> inter-cluster encoder -> out Linear -> mm_in_projector
+(mlp2x_gelu) — over ONE batch of 256 synthetic 224^2 images per GPU, bf16, inputs resident in HBM.
+Images shard embarrassingly: every rank encodes its own batch, there is no collective on the data
+path (weak scaling); the only collectives are the barrier and the MAX over ranks of the wall time.
+
+Rank 0 prints ONE JSON line with the driver's fields plus `roofline` (dominant kernel = the bf16
+MFMA GEMM; achieved = algorithmic FLOPs of the GEMM launches / their HIP-event durations measured
+inside the timed region on the launch stream) and `cpu_baseline` (the CPU oracle — a port of the
+reference's forward, validated against the reference in the build container — timed on this box's
+host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
+B_PER_GPU, IMG, PATCH = 256, 224, 14
+THRESHOLD, KNN = 0.125, 64         # dyn-k fires with seeded random-init features
+
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def build_model(device):
+    import setok_amd
+    from setok_amd.synthetic import init_synthetic_
+    vit = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+               image_size=IMG, patch_size=PATCH)
+    tok = setok_amd.SetokTokenizer(vision_tower=vit, mm_vision_select_layer=-2, hidden_dim=1024, token_feat_dim=4096,
+                                   min_cluster_num=64, threshold=THRESHOLD, nheads=2, dim_feedforward=4096)
+    init_synthetic_(tok, tower_seed=0, head_seed=1)
+    proj = setok_amd.build_vision_projector("mlp2x_gelu", mm_hidden_size=4096, hidden_size=4096)
+    torch.manual_seed(2)
+    for m in proj:
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight); torch.nn.init.zeros_(m.bias)
+    return tok.to(device=device, dtype=torch.bfloat16).eval(), proj.to(device=device, dtype=torch.bfloat16).eval()
+
+
+def cpu_baseline(tok, proj, n_images=8, reps=2):
+    """Oracle (oracle/setok_oracle.py) on the host cores: fp32, same weights (upcast from the bf16 model),
+    same synthetic image distribution, micro-batch of `n_images`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import setok_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))               # more threads than this only adds sync overhead to the small per-cluster ops
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in tok.state_dict().items()}
+    psd = {k: v.detach().float().cpu() for k, v in proj.state_dict().items()}
+    vc, hc = O.VitConfig(), O.HeadConfig(threshold=THRESHOLD)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(n_images, 3, IMG, IMG, generator=g)
+    t0 = time.perf_counter()
+    O.encode_images(sd, psd, "mlp2x_gelu", vc, hc, images[:2])          # warm-up, also sizes the sample
+    warm = time.perf_counter() - t0
+    if warm * n_images * reps / 2 > 60.0:                               # keep the leg bounded (~10-30 s of CPU work)
+        reps = 1
+        n_images = max(2, min(n_images, int(30.0 / (warm / 2))))
+        images = images[:n_images]
+    log(f"cpu_baseline: warm-up 2 images {warm:.1f} s on {cores} threads; timing {reps} x {n_images}")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = O.encode_images(sd, psd, "mlp2x_gelu", vc, hc, images)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_images * reps / dt, 3), unit="images/s", cores=cores, kind="port",
+                sample=f"{reps} x {n_images} images of the same workload (fp32, torch CPU, {cores} threads, {dt:.1f} s); "
+                       f"tokens/img {sum(o.shape[0] for o in out) / n_images:.1f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import setok_amd
+    from setok_amd import ops
+    log(f"rank {rank}/{world}: building model")
+    tok, proj = build_model(dev)
+    log("model on device")
+    B = args.batch
+    g = torch.Generator().manual_seed(3 + rank)
+    images = torch.randn(B, 3, IMG, IMG, generator=g).to(device=dev, dtype=torch.bfloat16)   # resident in HBM
+
+    def step():
+        return setok_amd.encode_images(tok, proj, images)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+    barrier()
+    ops.profile_start()                          # HIP events around every GEMM launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    log(f"timed {args.steps} steps in {dt:.3f} s")
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    counts = out.counts
+    if rank == 0:
+        gemm = [p for p in prof if p["kernel"] == "gemm_bf16"]
+        g_ms = sum(p["ms"] for p in gemm)
+        g_fl = sum(p["flops"] for p in gemm)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        res = {
+            "metric": "images/s SeTok encode (ViT-L/14, 224^2, dyn-k)",
+            "value": round(world * B * args.steps / dt, 2),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "cfg2: ViT-L/14 224^2 (23 of 24 layers, select_layer=-2), dyn-k DPC-kNN (k=64, "
+                                   "threshold=0.125), SeTok head 1024/2 heads/ff 4096 -> 4096, mm_in_projector mlp2x_gelu; "
+                                   "encode-only", "batch_per_gpu": B, "global_batch": world * B,
+                       "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
+                       "sharding": f"dp{world} (images sharded, no data-path collective)"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": len(gemm) // max(args.steps, 1),
+                         "avg_launch_ms": round(g_ms / max(len(gemm), 1), 4),
+                         "avg_launch_gflop": round(g_fl / max(len(gemm), 1) / 1e9, 2),
+                         "gemm_share_of_step": round(g_ms / (dt * 1e3), 3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(tok, proj)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

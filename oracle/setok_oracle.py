@@ -194,6 +194,12 @@ def cluster_dpc_knn(x: Tensor, k: int, threshold: float, min_cluster_num: int,
     (`torch.rand(N) * 1e-6`, :91) as an explicit input (None == zeros)."""
     N, C = x.shape
     dist = pairwise_dist(x) / (C ** 0.5)                                            # :82
+    return cluster_from_dist(dist, x.dtype, k, threshold, min_cluster_num, token_mask, noise)
+
+
+def cluster_from_dist(dist: Tensor, dtype, k: int, threshold: float, min_cluster_num: int,
+                      token_mask: Optional[Tensor] = None, noise: Optional[Tensor] = None) -> ClusterResult:
+    """tokenizer.py:84-121 given the scaled distance matrix of :82."""
     if token_mask is not None:                                                      # :84-86
         tm = token_mask > 0
         dist = dist * tm[None, :] + (dist.max() + 1) * (~tm[None, :])
@@ -203,7 +209,7 @@ def cluster_dpc_knn(x: Tensor, k: int, threshold: float, min_cluster_num: int,
         density = density + noise.to(density.dtype) * 1e-6                          # :91
     if token_mask is not None:
         density = density * tm                                                      # :93-94
-    mask = (density[None, :] > density[:, None]).to(x.dtype)                        # :96-97  mask[i,j] = rho_j > rho_i
+    mask = (density[None, :] > density[:, None]).to(dtype)                          # :96-97  mask[i,j] = rho_j > rho_i
     dist_max = dist.flatten(1).max(dim=-1)[0][None, None]                           # :98  (1,1,N): row-j max, indexed by LAST axis
     delta, _ = (dist * mask + dist_max * (1 - mask)).min(dim=-1)                    # :99  -> (1, N)
     score = delta * density                                                         # :101 -> (1, N)
@@ -217,35 +223,74 @@ def cluster_dpc_knn(x: Tensor, k: int, threshold: float, min_cluster_num: int,
     return ClusterResult(index_down, idx_cluster, score, density, delta.reshape(-1), dist, fallback)
 
 
-def cluster_fragile_tokens(x: Tensor, k: int, threshold: float, min_cluster_num: int,
-                           token_mask: Optional[Tensor] = None, noise: Optional[Tensor] = None,
-                           eps: float = 2e-6) -> Dict[str, Tensor]:
-    """Decision margins, computed in fp64 from the same fp32 inputs.  A decision whose margin is
-    below `eps` (fp32 rounding class for values of O(0.1..1)) may legitimately flip between two
-    correct fp32 implementations with different summation orders; parity tests demand bit-exact
-    integers everywhere else ("bit-exact indices are numerically fragile")."""
-    r = cluster_dpc_knn(x.double(), k, threshold, min_cluster_num, token_mask,
-                        None if noise is None else noise.double())
-    s = r.score.reshape(-1)
-    if not r.fallback:
-        centre_margin = (s - threshold).abs()
-    else:
-        srt = torch.sort(s, descending=True).values
-        kth, nxt = srt[min_cluster_num - 1], srt[min(min_cluster_num, s.numel() - 1)]
-        centre_margin = torch.minimum((s - kth).abs(), (s - nxt).abs())
-        centre_margin[torch.topk(s, min_cluster_num).indices[:-1]] = torch.maximum(
-            centre_margin[torch.topk(s, min_cluster_num).indices[:-1]], (kth - nxt).abs().expand(min_cluster_num - 1))
-    d = r.dist[r.index_down, :]
-    if d.shape[0] > 1:
-        two = torch.topk(d, 2, dim=0, largest=False).values
-        assign_margin = two[1] - two[0]
-    else:
-        assign_margin = torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
-    assign_margin[r.index_down] = float("inf")
-    return dict(index_down=r.index_down, idx_cluster=r.idx_cluster, score=s,
-                centre_margin=centre_margin, assign_margin=assign_margin,
-                centres_fragile=bool((centre_margin < eps).any()),
-                fragile=(assign_margin < eps))
+def cluster_sensitivity(x: Tensor, k: int, threshold: float, min_cluster_num: int,
+                        token_mask: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                        trials: int = 16, ulps: float = 4.0, seed: int = 0) -> Dict[str, Tensor]:
+    """Which discrete decisions of cluster_dpc_knn survive fp32-rounding-sized perturbations?
+
+    Two correct fp32 implementations of tokenizer.py:82 differ in the summation order of
+    |a|^2 + |b|^2 - 2 a.b, i.e. by a few ulps of (|a|^2 + |b|^2) in d^2 — a LARGE relative error for
+    near-duplicate tokens, which is why the reference itself adds tie-break noise (:91); densities that
+    tie within rounding flip the `rho_j > rho_i` mask and change delta discretely.  This runs the
+    algorithm in fp64 on the exact d^2 and on `trials` copies perturbed by N(0,1) * ulps * 2^-24 *
+    (|a|^2 + |b|^2); a decision is *certain* when all runs agree.  Parity tests demand bit-exact
+    integers for certain decisions and self-consistency for the rest (check_cluster_parity)."""
+    xd = x.double()
+    N, C = xd.shape
+    n = xd.pow(2).sum(-1)
+    d2 = (n[:, None] + n[None, :] - 2 * xd @ xd.t()).clamp_min(0)
+    scale = ulps * 2.0 ** -24 * (n[:, None] + n[None, :])
+    g = torch.Generator().manual_seed(seed)
+    nz = None if noise is None else noise.double()
+    runs = []
+    for t in range(trials + 1):
+        p = d2 if t == 0 else (d2 + scale * torch.randn(N, N, generator=g, dtype=torch.float64)).clamp_min(0)
+        runs.append(cluster_from_dist((p / C).sqrt(), torch.float64, k, threshold, min_cluster_num, token_mask, nz))
+    sel = torch.stack([torch.zeros(N, dtype=torch.bool).index_fill_(0, r.index_down, True) for r in runs])
+    centre_in, centre_out = sel.all(0), ~sel.any(0)
+    centres_certain = bool((centre_in | centre_out).all())
+    labels = torch.stack([r.idx_cluster for r in runs])
+    assign_certain = (labels == labels[0:1]).all(0) if centres_certain else torch.zeros(N, dtype=torch.bool)
+    scores = torch.stack([r.score.reshape(-1) for r in runs])
+    return dict(centre_in=centre_in, centre_out=centre_out, centres_certain=centres_certain,
+                assign_certain=assign_certain, index_down=runs[0].index_down, idx_cluster=runs[0].idx_cluster,
+                score=scores[0], score_lo=scores.min(0).values, score_hi=scores.max(0).values)
+
+
+def check_score(got_score: Tensor, sens: Dict[str, Tensor], rtol: float = 1e-3) -> None:
+    """`score` is a float by-product (the integers are the contract): it must lie inside the envelope
+    the perturbed fp64 runs span (a density near-tie moves delta, hence score, discretely), widened by
+    `rtol` for the d^2 cancellation error of near-duplicate tokens."""
+    g = got_score.reshape(-1).double()
+    lo, hi = sens["score_lo"] * (1 - rtol) - 1e-7, sens["score_hi"] * (1 + rtol) + 1e-7
+    bad = (g < lo) | (g > hi)
+    assert not bool(bad.any()), f"{int(bad.sum())} scores outside the fp32-perturbation envelope, e.g. token {int(bad.nonzero()[0])}"
+
+
+def check_cluster_parity(got_index_down: Tensor, got_idx_cluster: Tensor, ref_index_down: Tensor,
+                         ref_idx_cluster: Tensor, iv: Dict[str, Tensor]) -> Dict[str, int]:
+    """The integer contract: wherever cluster_sensitivity says a decision is certain, `got` must
+    equal `ref` bit for bit; everywhere it must be self-consistent (sorted centres, centres own
+    themselves, certainly-in tokens selected, certainly-out tokens not).  Raises AssertionError."""
+    N = got_idx_cluster.numel()
+    L = got_index_down.numel()
+    assert torch.equal(got_index_down, torch.sort(got_index_down).values) and got_index_down.unique().numel() == L
+    assert int(got_idx_cluster.min()) >= 0 and int(got_idx_cluster.max()) < L
+    assert torch.equal(got_idx_cluster[got_index_down], torch.arange(L)), "a centre does not own itself"
+    sel = torch.zeros(N, dtype=torch.bool); sel[got_index_down] = True
+    assert bool(sel[iv["centre_in"]].all()), "a certainly-selected centre is missing"
+    assert not bool(sel[iv["centre_out"]].any()), "a certainly-rejected token was selected"
+    stats = dict(centres_certain=int(iv["centres_certain"]), tokens_certain=0, tokens_compared=0)
+    if iv["centres_certain"]:
+        assert torch.equal(got_index_down, ref_index_down), "centre set differs although every centre decision is certain"
+        ok = iv["assign_certain"]
+        stats["tokens_certain"] = int(ok.sum())
+        bad = (got_idx_cluster != ref_idx_cluster) & ok
+        assert not bool(bad.any()), f"{int(bad.sum())} tokens with a certain assignment differ"
+    if torch.equal(got_index_down, ref_index_down):
+        stats["tokens_compared"] = N
+        stats["tokens_equal"] = int((got_idx_cluster == ref_idx_cluster).sum())
+    return stats
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,7 +1,166 @@
-// attn_vit.hip — bf16 MFMA attention for the ViT tower shape (uniform segments, head dim 64).
+// attn_vit.hip — bf16 MFMA self-attention for the ViT tower (uniform segments of T tokens, head dim 64).
+//
+// One workgroup per (image, head).  The head's K and V (T x 64 bf16 each, T <= 608) are staged ONCE
+// in LDS (K with a 16-B-slot XOR swizzle for conflict-free ds_read_b128; V row-major, consumed through
+// the gfx950 hardware-transposing ds_read_b64_tr_b16), then every wave owns 32 query rows and walks
+// the keys in tiles of 32 with an online softmax that never leaves registers:
+//   S^T = K Q^T  (v_mfma_f32_32x32x16_bf16, A = K fragment from LDS, B = Q fragment from HBM, kept in VGPRs)
+//        -> lane (q = lane & 31, hi = lane >> 5) holds 16 of the tile's 32 keys for ITS query row,
+//           so the row max / row sum are in-lane reductions plus one exchange with lane ^ 32;
+//   O^T += V^T P^T  (A = V^T fragment by two transposing reads, B = P packed to bf16 in place — the
+//           k-slot order of P's registers is matched by the order of the two V reads, so P needs no
+//           cross-lane movement at all).
+// HBM traffic per (image, head): read Q, K, V once, write O once — the algorithmic minimum.
 #include "common.h"
 
+namespace {
+
+constexpr int DH = 64;
+constexpr int ROWB = DH * 2;            // 128 bytes per K / V row in LDS
+
+typedef __attribute__((ext_vector_type(4))) short short4v;
+
+__device__ inline bf16x8 pack8(const float* p) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)p[i];
+    return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                           int T, int H, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int Tp = (T + 31) & ~31;
+    char* Ks = lds;
+    char* Vs = lds + (size_t)Tp * ROWB;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = H * DH;
+    const int64_t ld = 3LL * C;
+    const bf16* base = qkv + (int64_t)b * T * ld + h * DH;
+
+    // ---- stage K (swizzled) and V (row-major) of this head in LDS; zero the padding rows ----------
+    for (int idx = tid; idx < Tp * 8; idx += NW * 64) {
+        const int key = idx >> 3, c = idx & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < T) {
+            const bf16* p = base + (int64_t)key * ld + c * 8;
+            kv = *reinterpret_cast<const uint4*>(p + C);
+            vv = *reinterpret_cast<const uint4*>(p + 2 * C);
+        }
+        *reinterpret_cast<uint4*>(Ks + key * ROWB + ((c ^ (key & 7)) << 4)) = kv;
+        *reinterpret_cast<uint4*>(Vs + key * ROWB + (c << 4)) = vv;
+    }
+    __syncthreads();
+
+    const int qi = lane & 31, hi = lane >> 5;
+    const int nq = (T + 31) >> 5, nkv = Tp >> 5;
+    // transposing-read address pattern: lanes 4j+p of a 16-lane group supply row j, 4-column piece p
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int tr_row = (i16 >> 2) + 4 * (g16 >> 1);            // + 4*hi
+    const int tr_col = (g16 & 1) * 16 + (i16 & 3) * 4;         // column of this lane's 8-byte piece
+
+    for (int qt = wave; qt < nq; qt += NW) {
+        const int q = qt * 32 + qi;
+        const bf16* qp = base + (int64_t)min(q, T - 1) * ld + hi * 8;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+
+        f32x16 o[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+        for (int kt = 0; kt < nkv; ++kt) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const int krow = kt * 32 + qi;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow * ROWB + (((ks * 2 + hi) ^ (krow & 7)) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // s[r]: key = kt*32 + (r&3) + 8*(r>>2) + 4*hi, query = q
+            float t[16];
+            float mx = -INFINITY;
+            const bool tail = (kt == nkv - 1) && (Tp != T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[r] = s[r] * scale_log2e;
+                if (tail) { const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; if (key >= T) t[r] = -INFINITY; }
+                mx = fmaxf(mx, t[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { t[r] = __builtin_amdgcn_exp2f(t[r] - m_new); ls += t[r]; }
+            l_run = l_run * alpha + ls;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            const bf16x8 p0 = pack8(t), p1 = pack8(t + 8);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const char* vb = Vs + (kt * 32 + k2 * 16 + tr_row) * ROWB + (d * 32 + tr_col) * 2;
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb));
+                    const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb + 8 * ROWB));
+                    union { short s8[8]; bf16x8 v; } u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { u.s8[j] = lo[j]; u.s8[4 + j] = hi4[j]; }
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, k2 == 0 ? p0 : p1, o[d], 0, 0, 0);
+                }
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (q < T) {
+            bf16* op = out + ((int64_t)b * T + q) * C + h * DH;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[d][r4 * 4 + j] * inv);
+                    *reinterpret_cast<bf16x4*>(op + d * 32 + 8 * r4 + 4 * hi) = v;   // dims (r&3) + 8*(r>>2) + 4*hi
+                }
+        }
+    }
+}
+
+template <int NW>
+int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, float scale) {
+    const int Tp = (T + 31) & ~31;
+    const size_t smem = (size_t)Tp * ROWB * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
+        attr_set = true;
+    }
+    attn_vit_kernel<NW><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f);
+    SETOK_CHECK_LAUNCH("setok_attention(vit bf16)");
+    return SETOK_OK;
+}
+
+}  // namespace
+
 int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, int Dh, float scale) {
-    (void)s; (void)qkv; (void)out; (void)n_imgs; (void)T; (void)H; (void)Dh; (void)scale;
-    return SETOK_EUNSUPPORTED;   // falls back to the generic kernel (norm_attn.hip) until the MFMA kernel lands
+    if (Dh != DH || T < 1 || (size_t)((T + 31) & ~31) * ROWB * 2 > 160 * 1024) return SETOK_EUNSUPPORTED;
+    const int nq = (T + 31) >> 5;
+    if (nq >= 9) return launch<9>(s, qkv, out, n_imgs, T, H, scale);
+    if (nq >= 7) return launch<7>(s, qkv, out, n_imgs, T, H, scale);
+    if (nq >= 4) return launch<4>(s, qkv, out, n_imgs, T, H, scale);
+    return launch<1>(s, qkv, out, n_imgs, T, H, scale);
 }

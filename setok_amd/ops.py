@@ -48,6 +48,23 @@ def k_align(dt: torch.dtype) -> int:
     return 64 if dt == torch.bfloat16 else 16
 
 
+# ---- optional launch profiler (bench.py): HIP events on the launch stream around every GEMM -------------
+_PROFILE = None
+
+
+def profile_start() -> None:
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop():
+    """Synchronise and return [{kernel, flops, ms}] for every launch recorded since profile_start()."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE or [], None
+    torch.cuda.synchronize()
+    return [dict(kernel=k, flops=f, ms=e0.elapsed_time(e1)) for k, f, e0, e1 in rec]
+
+
 def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
            act: int = ACT_NONE, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
     """out = act(a @ w.T + bias) + residual;  a: (M, K), w: (N, K), bias fp32 (N,)."""
@@ -60,8 +77,14 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Option
     assert out.shape == (M, N) and out.dtype == od
     if residual is not None:
         assert residual.shape == (M, N) and residual.dtype == od
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("setok_linear", _stream(), _code(a.dtype), _code(od), _p(a), K, _p(w), _p(_f32(bias)), _p(residual),
               _p(out), N, M, N, K, act, 1, 0, 0, 0)
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append(("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, e0, e1))
     return out
 
 

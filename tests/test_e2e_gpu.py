@@ -104,14 +104,12 @@ def test_vitl_head_from_reference_features(golden_dir):
     toks, idx, score, st = tok.encode_features(hidden, 2, return_stages=True)
     x = feats + O.pos_encoding_2d(16, 16, 1024)[None]
     for i in range(2):
-        fr = O.cluster_fragile_tokens(x[i], 64, 0.125, 64)
-        assert not fr["centres_fragile"]
-        ref_idx = _t(z[f"{i}:idx_cluster"]).long()
-        assert st["counts"][i] == _t(z[f"{i}:index_down"]).numel()
-        same = idx[i].cpu() == ref_idx
-        assert bool((same | fr["fragile"]).all())
-        if bool(same.all()):
-            assert _rel(toks[i], _t(z[f"{i}:tokens"])) < TOL
+        sens = O.cluster_sensitivity(x[i], 64, 0.125, 64)
+        L = st["counts"][i]
+        stats = O.check_cluster_parity(st["index_down"][i, :L].cpu(), idx[i].cpu(), _t(z[f"{i}:index_down"]).long(),
+                                       _t(z[f"{i}:idx_cluster"]).long(), sens)
+        assert sens["centres_certain"] and stats["tokens_equal"] == 256          # bit-exact indices and token count
+        assert _rel(toks[i], _t(z[f"{i}:tokens"])) < TOL
     start = 0
     for i in range(2):
         L = st["counts"][i]
@@ -134,10 +132,14 @@ def test_vitl_tower_fp32_parity(golden_dir):
     x = _t(z["feats"]) + O.pos_encoding_2d(16, 16, 1024)[None]
     n_diff = 0
     for i in range(2):
-        fr = O.cluster_fragile_tokens(x[i], 64, 0.125, 64, eps=2e-5)     # tower features differ by ~1e-5 relative
+        # the tower features differ from the reference's by ~1e-5 relative (different fp32 summation order
+        # through 23 layers), i.e. ~100 ulps of |x|^2 in d^2: widen the perturbation accordingly
+        sens = O.cluster_sensitivity(x[i], 64, 0.125, 64, ulps=256.0)
         same = idx[i].cpu() == _t(z[f"{i}:idx_cluster"]).long()
         n_diff += int((~same).sum())
-        assert bool((same | fr["fragile"]).all()) or fr["centres_fragile"]
+        if sens["centres_certain"]:
+            assert toks[i].shape[0] == _t(z[f"{i}:index_down"]).numel()
+            assert bool((same | ~sens["assign_certain"]).all())
     print("vitl fp32 from pixels: tokens with a different cluster id:", n_diff, "of 512")
 
 

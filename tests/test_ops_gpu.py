@@ -144,24 +144,6 @@ def test_assemble_and_select(dt):
 # ---------------------------------------------------------------------------------------------
 # clustering against the reference's golden vectors (integers bit-exact)
 # ---------------------------------------------------------------------------------------------
-def _score_ok(score_gpu, score_ref32, x, k, thr, mcn, noise=None, token_mask=None):
-    """score is a float by-product (the integers are the contract).  d^2 = |a|^2 + |b|^2 - 2 a.b cancels
-    catastrophically for near-duplicate tokens, so two correct fp32 implementations differ by far more
-    than 1 ulp there; judge both against the same algorithm in fp64: the GPU must be as close to the
-    exact answer as the reference's own fp32 run (x8 slack: with |x|^2 ~ 4600 one ulp of n_i + n_j is
-    already 1e-4 of a d^2 ~ 5), or within 2e-5 relative."""
-    r64 = O.cluster_dpc_knn(x.double(), k, thr, mcn, token_mask, None if noise is None else noise.double()).score.reshape(-1)
-    e_gpu = (score_gpu.reshape(-1).double() - r64).abs()
-    e_ref = (score_ref32.reshape(-1).double() - r64).abs()
-    bound = torch.maximum(8 * e_ref.max().expand_as(e_ref), 2e-5 * r64.abs() + 1e-7)
-    ok = bool((e_gpu <= bound).all())
-    if not ok:
-        i = int((e_gpu - bound).argmax())
-        print(f"score check: worst token {i}: gpu err {float(e_gpu[i]):.3e} (rel {float(e_gpu[i] / r64[i]):.3e}) bound {float(bound[i]):.3e} "
-              f"ref32 err max {float(e_ref.max()):.3e}; gpu err max {float(e_gpu.max()):.3e} rel max {float((e_gpu / r64.abs()).max()):.3e}")
-    return ok
-
-
 def _cluster_gpu(x, k, thr, mcn, noise=None, token_mask=None):
     N = x.shape[0]
     idx, score, index_down, counts = ops.cluster_dpc_knn(
@@ -181,48 +163,50 @@ def test_cluster_head_small_golden(golden_dir):
         nz = torch.from_numpy(z[f"{case}:noise"]) if f"{case}:noise" in z.files else None
         tm = torch.from_numpy(z[f"{case}:token_mask"]) if f"{case}:token_mask" in z.files else None
         idx, score, centres, L, pad = _cluster_gpu(x, k, thr, 8, nz, tm)
+        sens = O.cluster_sensitivity(x, k, thr, 8, tm, nz)
+        assert sens["centres_certain"] and bool(sens["assign_certain"].all()), case      # fixtures chosen with wide margins
+        O.check_cluster_parity(centres, idx, torch.from_numpy(z[f"{case}:index_down"]), torch.from_numpy(z[f"{case}:idx_cluster"]), sens)
         assert torch.equal(centres, torch.from_numpy(z[f"{case}:index_down"])), case
         assert torch.equal(idx, torch.from_numpy(z[f"{case}:idx_cluster"])), case
         assert bool((pad == -1).all())
-        assert _score_ok(score, torch.from_numpy(z[f"{case}:score"]), x, k, thr, 8, nz, tm), case
+        O.check_score(score, sens)
 
 
 def test_cluster_full_dims_golden(golden_dir):
     z = np.load(os.path.join(golden_dir, "cluster_full.npz"))
+    n_exact = 0
     for name in sorted({k.split(":")[0] for k in z.files}):
         N, C, m, seed, k, mcn, thr = z[name + ":spec"]
         N, C, m, seed, k, mcn = int(N), int(C), int(m), int(seed), int(k), int(mcn)
         h = int(N ** 0.5)
         x = O.planted_features(N, C, m, seed=seed) + O.pos_encoding_2d(h, h, C)
         idx, score, centres, L, _ = _cluster_gpu(x, k, float(thr), mcn)
-        assert torch.equal(centres, torch.from_numpy(z[name + ":index_down"]).long()), name
-        assert torch.equal(idx, torch.from_numpy(z[name + ":idx_cluster"]).long()), name
-        assert _score_ok(score, torch.from_numpy(z[name + ":score"]), x, k, float(thr), mcn), name
+        sens = O.cluster_sensitivity(x, k, float(thr), mcn)
+        st = O.check_cluster_parity(centres, idx, torch.from_numpy(z[name + ":index_down"]).long(),
+                                    torch.from_numpy(z[name + ":idx_cluster"]).long(), sens)
+        n_exact += st["centres_certain"]
+        if st["centres_certain"]:
+            assert st["tokens_certain"] == N and st.get("tokens_equal") == N, (name, st)
+        O.check_score(score, sens)
+    assert n_exact >= 10        # only the two top-32 fallback cases sit on a rounding-level score tie (sensitivity analysis)
 
 
 def test_cluster_vitl_reference_features(golden_dir):
-    """Dynamic-k on the reference's own ViT-L tower features; bit-exact wherever the decision margin
-    (fp64 analysis of the same inputs) exceeds fp32 rounding."""
+    """Dynamic-k and fallback branches on the reference's own ViT-L tower features (cfg2 dims)."""
     z = np.load(os.path.join(golden_dir, "vitl_224.npz"))
     feats = torch.from_numpy(z["feats"])
     x = feats + O.pos_encoding_2d(16, 16, 1024)[None]
-    idx, score, index_down, counts = ops.cluster_dpc_knn(x.to(DEV).reshape(-1, 1024), 2, 256, 64, 0.125, 64)
-    for i in range(2):
-        L = int(counts[i])
-        fr = O.cluster_fragile_tokens(x[i], 64, 0.125, 64)
-        ref_c = torch.from_numpy(z[f"{i}:index_down"]).long()
-        ref_i = torch.from_numpy(z[f"{i}:idx_cluster"]).long()
-        if not fr["centres_fragile"]:
-            assert L == ref_c.numel() and torch.equal(index_down[i, :L].cpu(), ref_c)
-            ok = (idx[i].cpu() == ref_i) | fr["fragile"]
-            assert bool(ok.all()), f"image {i}: {int((~ok).sum())} non-fragile tokens differ"
-        assert _score_ok(score[i].cpu(), torch.from_numpy(z[f"{i}:score"]), x[i], 64, 0.125, 64)
-    # fallback branch (threshold 0.5 -> 64 best scores)
-    idx, score, index_down, counts = ops.cluster_dpc_knn(x.to(DEV).reshape(-1, 1024), 2, 256, 64, 0.5, 64)
-    for i in range(2):
-        assert int(counts[i]) == 64
-        assert torch.equal(index_down[i, :64].cpu(), torch.from_numpy(z[f"{i}:fb:index_down"]).long())
-        assert torch.equal(idx[i].cpu(), torch.from_numpy(z[f"{i}:fb:idx_cluster"]).long())
+    for thr, pre in ((0.125, ""), (0.5, "fb:")):
+        idx, score, index_down, counts = ops.cluster_dpc_knn(x.to(DEV).reshape(-1, 1024), 2, 256, 64, thr, 64)
+        for i in range(2):
+            L = int(counts[i])
+            sens = O.cluster_sensitivity(x[i], 64, thr, 64)
+            assert sens["centres_certain"] and bool(sens["assign_certain"].all())
+            ref_c = torch.from_numpy(z[f"{i}:{pre}index_down"]).long()
+            ref_i = torch.from_numpy(z[f"{i}:{pre}idx_cluster"]).long()
+            st = O.check_cluster_parity(index_down[i, :L].cpu(), idx[i].cpu(), ref_c, ref_i, sens)
+            assert st["tokens_equal"] == 256
+            O.check_score(score[i].cpu(), sens)
 
 
 def test_cluster_batched_equals_per_image_and_bf16_runs():
@@ -231,15 +215,15 @@ def test_cluster_batched_equals_per_image_and_bf16_runs():
     idx, score, index_down, counts = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, 8, 0.5, 64)
     for i in range(B):
         r = O.cluster_dpc_knn(xs[i], 8, 0.5, 64)
-        assert int(counts[i]) == r.index_down.numel()
-        assert torch.equal(idx[i].cpu(), r.idx_cluster)
+        O.check_cluster_parity(index_down[i, :int(counts[i])].cpu(), idx[i].cpu(), r.index_down, r.idx_cluster,
+                               O.cluster_sensitivity(xs[i], 8, 0.5, 64))
     # bf16 inputs: same algorithm on the bf16-rounded features (exact products, fp32 accumulate)
     xb = xs.bfloat16()
-    idx_b, _, _, counts_b = ops.cluster_dpc_knn(xb.to(DEV).reshape(-1, C), B, N, 8, 0.5, 64)
+    idx_b, _, down_b, counts_b = ops.cluster_dpc_knn(xb.to(DEV).reshape(-1, C), B, N, 8, 0.5, 64)
     for i in range(B):
         r = O.cluster_dpc_knn(xb[i].float(), 8, 0.5, 64)
-        assert int(counts_b[i]) == r.index_down.numel()
-        assert torch.equal(idx_b[i].cpu(), r.idx_cluster)
+        O.check_cluster_parity(down_b[i, :int(counts_b[i])].cpu(), idx_b[i].cpu(), r.index_down, r.idx_cluster,
+                               O.cluster_sensitivity(xb[i].float(), 8, 0.5, 64))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -149,3 +149,26 @@ def test_projector_types():
     assert O.projector_forward({}, "identity", x) is x
     with pytest.raises(ValueError):
         O.projector_forward({}, "bogus", x)
+
+
+def test_sensitivity_analysis_accepts_reference_outputs(golden_dir):
+    """The perturbation analysis that decides which integer decisions parity tests must match
+    bit-for-bit (oracle.cluster_sensitivity) must itself accept the reference's own fp32 outputs, and
+    must flag the known rounding-level tie (top-32 fallback on planted features: the reference's fp32
+    run and an exact fp64 run pick different 32nd centres)."""
+    z = _load(golden_dir, "cluster_full")
+    n_certain = 0
+    for name in sorted({k.split(":")[0] for k in z.files}):
+        N, C, m, seed, k, mcn, thr = z[name + ":spec"]
+        N, C, m, seed, k, mcn = int(N), int(C), int(m), int(seed), int(k), int(mcn)
+        if N != 256:
+            continue
+        x = O.planted_features(N, C, m, seed=seed) + O.pos_encoding_2d(16, 16, C)
+        sens = O.cluster_sensitivity(x, k, float(thr), mcn)
+        ref_c, ref_i = _t(z[name + ":index_down"]).long(), _t(z[name + ":idx_cluster"]).long()
+        st = O.check_cluster_parity(ref_c, ref_i, ref_c, ref_i, sens)
+        O.check_score(_t(z[name + ":score"]), sens)
+        n_certain += st["centres_certain"]
+        if "mcn32" in name:
+            assert not sens["centres_certain"]
+    assert n_certain == 5
