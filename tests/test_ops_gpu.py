@@ -58,6 +58,24 @@ def test_linear_bf16(M, N, K, act):
     assert _rel_err(got32, ref) < 2e-5            # bf16 products are exact in fp32; only the accumulation order differs
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(4096, 4096, 1024, 1, True), (4100, 2056, 128, 0, False), (2560, 3072, 256, 2, True),
+                                           (6000, 1024, 4096, 0, True)])
+def test_linear_bf16_large_tiles(M, N, K, act, res):
+    """Shapes with >= 96 output tiles take the 256x256 direct-to-LDS kernel (ragged M and N edges included)."""
+    a, w = _rand(M, K, seed=1).bfloat16(), (_rand(N, K, seed=2, scale=K ** -0.5)).bfloat16()
+    b = _rand(N, seed=3)
+    r = _rand(M, N, seed=4).bfloat16() if res else None
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = [ref, O.quick_gelu(ref), F.gelu(ref)][act]
+    if res:
+        ref = ref.bfloat16().double() + r.double()         # torch-bf16 semantics: the Linear output is rounded, then added
+    got = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), None if r is None else r.to(DEV), act=act)
+    assert _rel_err(got, ref) < 6e-3
+    # element-wise: at most one bf16 ulp (2^-8 relative) + accumulation-order noise
+    err = (got.double().cpu() - ref).abs()
+    assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all())
+
+
 def test_linear_transpose_detecting():
     """A = I with an asymmetric W catches a swapped C/D fragment mapping (cdna guide rule 16)."""
     K = 128
