@@ -57,7 +57,7 @@ def build_model(device):
     return tok.to(device=device, dtype=torch.bfloat16).eval(), proj.to(device=device, dtype=torch.bfloat16).eval()
 
 
-def cpu_baseline(tok, proj, n_images=8, reps=2):
+def cpu_baseline(tok, proj, n_images=16, reps=3):
     """Oracle (oracle/setok_oracle.py) on the host cores: fp32, same weights (upcast from the bf16 model),
     same synthetic image distribution, micro-batch of `n_images`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -166,7 +166,7 @@ def main():
                                    "encode-only", "batch_per_gpu": B, "global_batch": world * B,
                        "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
                        "sharding": f"dp{world} (images sharded, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<4,*> (bf16 MFMA GEMM of every large Linear)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launches_per_step": len(gemm) // max(args.steps, 1),
                          "avg_launch_ms": round(g_ms / max(len(gemm), 1), 4),

@@ -9,6 +9,8 @@
 //    staging, LDS double-buffered, one barrier per K tile.  LDS rows are 128 B with a 16-B-slot XOR
 //    swizzle (slot ^= row & 7) so a ds_read_b128 lane group is <= 2-way conflicted
 //    (cdna_hip_programming.md T2).
+//  * the big bf16 Linear layers (>= 96 output tiles of 256x256) go to the persistent direct-to-LDS kernel
+//    in gemm_persist.hip; the kernel below serves small problems, fp32 outputs (Gram matrix) and batches.
 //  * fp32 kernel  (parity mode): 64x64x16 block tile, 4 waves, v_mfma_f32_32x32x2_f32 — bit-for-bit a
 //    k-ordered fmaf chain, so results do not depend on tile geometry.
 #include "common.h"
@@ -131,154 +133,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         }
 }
 
-// --------------------------------------------------------------------------------------------
-// bf16 256x256x64, 8 waves, direct-to-LDS loads — the throughput kernel for the big GEMMs.
-//
-//  * one workgroup (512 threads, 2 waves per SIMD) owns a 256x256 output tile; wave (wm, wn) owns
-//    128 (M) x 64 (N) = 4x2 MFMA tiles of 32x32 (128 accumulator VGPRs);
-//  * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip): the LDS image is
-//    lane-linear, so the 16-B-slot XOR swizzle is applied to the per-lane SOURCE address and to the
-//    ds_read_b128 address (cdna guide rule 21); two 64 KiB stages, the loads of K-tile t+1 are in
-//    flight while tile t is multiplied; one barrier per K-tile;
-//  * MFMA operands are swapped (A-operand = W fragment, B-operand = activation fragment), so a lane
-//    holds, for ONE output row, 4 consecutive output columns per accumulator quad -> the epilogue
-//    applies bias/activation in registers, stages the bf16 tile through LDS (8-byte writes) and
-//    emits full 128-byte rows with 16-byte stores, adding the residual from a coalesced 16-byte read;
-//  * blockIdx is remapped so that the 32 workgroups resident on one XCD (private 4 MiB L2) form an
-//    8 (M) x 4 (N) patch of tiles and share operand panels (cdna guide T1).
-// --------------------------------------------------------------------------------------------
-constexpr int TM = 256, TN = 256, TK = 64;
-constexpr int T_STAGE = (TM + TN) * TK * 2;        // 64 KiB
-constexpr int T_BOFF = TM * TK * 2;
-
-template <int ACT>
-__global__ __launch_bounds__(512) void gemm_bf16_256_kernel(GemmArgs g, int tilesM, int tilesN) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    // ---- XCD-aware, grouped tile order --------------------------------------------------------
-    const int nwg = tilesM * tilesN;
-    int id = blockIdx.x;
-    {
-        const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    }
-    constexpr int GM = 8;
-    const int group = id / (GM * tilesN), first_m = group * GM;
-    const int gm = min(tilesM - first_m, GM);
-    const int tm = first_m + (id % (GM * tilesN)) % gm, tn = (id % (GM * tilesN)) / gm;
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    const bf16* A = (const bf16*)g.A;
-    const bf16* W = (const bf16*)g.W;
-
-    // ---- direct-to-LDS staging: chunk p = i*512 + tid (16 B each) -> row = p>>3, slot = p&7 ------
-    const bf16* a_src[4]; const bf16* b_src[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ (row & 7);
-        a_src[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-        b_src[i] = W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
-    }
-    auto issue_loads = [&](int stage, int k0) {
-        char* sb = smem + stage * T_STAGE + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sb + i * 8192), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sb + T_BOFF + i * 8192), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int frow = lane & 31, hi = lane >> 5;
-    const int nk = g.K / TK;
-    issue_loads(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): this wave's pieces of tile kt have landed
-        __syncthreads();                          // ... everyone's have, and everyone left tile kt-1's stage
-        if (kt + 1 < nk) issue_loads((kt + 1) & 1, (kt + 1) * TK);
-        const char* Ab = smem + (kt & 1) * T_STAGE;
-        const char* Bb = Ab + T_BOFF;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 wf[2], af[4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int r = wn * 64 + t * 32 + frow;
-                wf[t] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((ks * 2 + hi) ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = wm * 128 + t * 32 + frow;
-                af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();                              // all MFMA operand reads done: LDS becomes the C staging area
-
-    // ---- epilogue -------------------------------------------------------------------------------
-    // acc[i][j][r]: output row m = wm*128 + i*32 + (lane&31), column n = wn*64 + j*32 + (r&3) + 8*(r>>2) + 4*hi
-    char* stg = smem + wave * (128 * 128);        // 128 rows x 64 bf16 per wave, 16-B slots XOR-swizzled by row
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int ncol = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * hi;
-            float bv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = (g.bias && ncol + e < g.N) ? g.bias[ncol + e] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][q4 * 4 + e] + bv[e];
-                    if (ACT == SETOK_ACT_QUICK_GELU) x = x / (1.0f + __expf(-1.702f * x));
-                    else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-                    v[e] = (bf16)x;
-                }
-                const int row = i * 32 + frow;
-                *reinterpret_cast<bf16x4*>(stg + row * 128 + (((j * 4 + q4) ^ (row & 7)) << 4) + 8 * hi) = v;
-            }
-        }
-    // each wave re-reads only its own staging area: no workgroup barrier needed, only LDS write->read ordering
-    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0)
-    bf16* C = (bf16*)g.C;
-    const bf16* R = (const bf16*)g.res;
-    const int slot = lane & 7;
-    const int col = n0 + wn * 64 + slot * 8;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const int grow = m0 + wm * 128 + row;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
-        if (grow < g.M && col < g.N) {
-            const int64_t o = (int64_t)grow * g.ldc + col;
-            if (R) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + o);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[e]);
-            }
-            *reinterpret_cast<bf16x8*>(C + o) = v;
-        }
-    }
-}
+int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
+                            bf16* C, int64_t ldc, int M, int N, int K, int act);    // gemm_persist.hip
 
 // --------------------------------------------------------------------------------------------
 // fp32 64x64x16  (exact f32 MFMA; parity mode)
@@ -377,22 +233,9 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
     if (dtype == SETOK_BF16) {
         SETOK_CHECK_ARG(K % BK == 0, "setok_linear(bf16): K=%d must be a multiple of %d", K, BK);
         SETOK_CHECK_ARG(lda % 8 == 0, "setok_linear(bf16): lda must be a multiple of 8");
-        const int tilesM = cdiv(M, TM), tilesN = cdiv(N, TN);
-        if (out_dtype == SETOK_BF16 && batch == 1 && N % 8 == 0 && ldc % 8 == 0 && tilesM * tilesN >= 96 && !g_force_small_tiles) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                bool ok = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T_STAGE) == hipSuccess;
-                ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T_STAGE) == hipSuccess;
-                ok = ok && hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T_STAGE) == hipSuccess;
-                if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise dynamic LDS limit");
-                attr_set = true;
-            }
-            if (act == SETOK_ACT_NONE) gemm_bf16_256_kernel<0><<<tilesM * tilesN, 512, 2 * T_STAGE, s>>>(g, tilesM, tilesN);
-            else if (act == SETOK_ACT_QUICK_GELU) gemm_bf16_256_kernel<1><<<tilesM * tilesN, 512, 2 * T_STAGE, s>>>(g, tilesM, tilesN);
-            else gemm_bf16_256_kernel<2><<<tilesM * tilesN, 512, 2 * T_STAGE, s>>>(g, tilesM, tilesN);
-            SETOK_CHECK_LAUNCH("setok_linear(256)");
-            return SETOK_OK;
-        }
+        // big problems (>= 96 tiles of 256x256): persistent direct-to-LDS kernel (gemm_persist.hip)
+        if (out_dtype == SETOK_BF16 && batch == 1 && N % 8 == 0 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 96 && !g_force_small_tiles)
+            return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
         dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
         if (out_dtype == SETOK_BF16) gemm_bf16_kernel<bf16, true><<<grid, 256, 0, s>>>(g);
         else if (out_dtype == SETOK_F32) gemm_bf16_kernel<float, false><<<grid, 256, 0, s>>>(g);

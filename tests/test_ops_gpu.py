@@ -59,7 +59,8 @@ def test_linear_bf16(M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(4096, 4096, 1024, 1, True), (4100, 2056, 128, 0, False), (2560, 3072, 256, 2, True),
-                                           (6000, 1024, 4096, 0, True)])
+                                           (6000, 1024, 4096, 0, True), (8448, 2048, 512, 1, True), (65792, 1024, 128, 0, True),
+                                           (16640, 4096, 64, 2, False)])
 def test_linear_bf16_large_tiles(M, N, K, act, res):
     """Shapes with >= 96 output tiles take the 256x256 direct-to-LDS kernel (ragged M and N edges included)."""
     a, w = _rand(M, K, seed=1).bfloat16(), (_rand(N, K, seed=2, scale=K ** -0.5)).bfloat16()
