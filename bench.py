@@ -142,12 +142,15 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.profile_stop()
     log(f"timed {args.steps} steps in {dt:.3f} s")
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from setok_amd.parallel import max_over_ranks
+    dt = max_over_ranks(dt, device=dev)            # wall time of the slowest rank
 
     counts = out.counts
+    traffic = None                  # HBM bytes per GEMM launch from the PMC passes of the same command (profiles/)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         gemm = [p for p in prof if p["kernel"] == "gemm_bf16"]
         g_ms = sum(p["ms"] for p in gemm)
@@ -167,7 +170,7 @@ def main():
                        "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
                        "sharding": f"dp{world} (images sharded, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<4,*> (bf16 MFMA GEMM of every large Linear)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": len(gemm) // max(args.steps, 1),
                          "avg_launch_ms": round(g_ms / max(len(gemm), 1), 4),
                          "avg_launch_gflop": round(g_fl / max(len(gemm), 1) / 1e9, 2),

@@ -1,0 +1,80 @@
+"""The N > 1 path (sharding, ragged gather, bucketed gradient all-reduce, MAX-over-ranks timing) under
+world_size = 2 with the gloo backend on CPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from setok_amd import parallel as P
+    try:
+        # 1. sharding: contiguous, disjoint, covering
+        n = 257
+        s, e = P.shard_range(n, rank, world)
+        spans = [None] * world
+        dist.all_gather_object(spans, (s, e))
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+        images = torch.arange(n * 2, dtype=torch.float32).reshape(n, 2)
+        assert torch.equal(P.shard_batch(images, rank, world), images[s:e])
+        # 2. ragged gather: per-image token counts differ per rank (dynamic-k)
+        g = torch.Generator().manual_seed(100 + rank)
+        counts = torch.randint(1, 9, (e - s,), generator=g).tolist()
+        packed = torch.cat([torch.full((c, 3), float(s + i)) for i, c in enumerate(counts)])
+        rows, all_counts = P.gather_ragged(packed, counts)
+        assert len(all_counts) == n and rows.shape[0] == sum(all_counts)
+        off = 0
+        for i, c in enumerate(all_counts):                      # image order == global order, rows labelled by image id
+            assert bool((rows[off:off + c] == float(i)).all()); off += c
+        # 3. bucketed gradient all-reduce == mean of per-rank gradients, several buckets
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(sz)) for sz in (1000, 37, 4096, 5)]
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        ncoll = P.allreduce_gradients(params, bucket_bytes=8192)
+        assert ncoll >= 2
+        for i, p in enumerate(params):
+            assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * (1 + world) / 2.0))
+        # 4. timing rule
+        assert P.max_over_ranks(1.0 + rank) == float(world)
+        q.put((rank, "ok"))
+    except Exception as ex:  # pragma: no cover
+        q.put((rank, repr(ex)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_range_edge_cases():
+    from setok_amd import parallel as P
+    assert [P.shard_range(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
+    assert P.shard_range(256, 3, 8) == (96, 128)
+    assert P.max_over_ranks(0.5) == 0.5          # not initialised -> identity

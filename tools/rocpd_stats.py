@@ -15,7 +15,7 @@ def main(db, out=None):
     rows.sort(key=lambda r: -r[2])
     lines = ["kernel,calls,total_ms,avg_us,min_us,max_us,share"]
     for n, cnt, t, mn, mx in rows:
-        short = re.sub(r"\(.*", "", n)[:90]
+        short = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", ""))[:90]
         lines.append(f"\"{short}\",{cnt},{t / 1e6:.3f},{t / cnt / 1e3:.2f},{mn / 1e3:.2f},{mx / 1e3:.2f},{t / tot:.4f}")
     lines.append(f"\"TOTAL\",{sum(r[1] for r in rows)},{tot / 1e6:.3f},,,,1.0")
     text = "\n".join(lines)
