@@ -85,28 +85,33 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow * ROWB + (((ks * 2 + hi) ^ (krow & 7)) << 4));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
-            // s[r]: key = kt*32 + (r&3) + 8*(r>>2) + 4*hi, query = q
+            // s[r]: key = kt*32 + (r&3) + 8*(r>>2) + 4*hi, query = q.  The running max is kept in raw score units;
+            // softmax scale and log2(e) are folded into one fma per element: p = exp2(s*c - m*c).
             float t[16];
             float mx = -INFINITY;
             const bool tail = (kt == nkv - 1) && (Tp != T);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                t[r] = s[r] * scale_log2e;
+                t[r] = s[r];
                 if (tail) { const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; if (key >= T) t[r] = -INFINITY; }
                 mx = fmaxf(mx, t[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            if (!__all(m_new == m_run)) {                 // wave-uniform: most tiles after the first few do not raise any row max
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = m_run * scale_log2e;
             float ls = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { t[r] = __builtin_amdgcn_exp2f(t[r] - m_new); ls += t[r]; }
-            l_run = l_run * alpha + ls;
-            m_run = m_new;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            for (int r = 0; r < 16; ++r) { t[r] = __builtin_amdgcn_exp2f(fmaf(t[r], scale_log2e, -mc)); ls += t[r]; }
+            l_run += ls;
             const bf16x8 p0 = pack8(t), p1 = pack8(t + 8);
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
@@ -159,7 +164,11 @@ int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, 
 int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, int Dh, float scale) {
     if (Dh != DH || T < 1 || (size_t)((T + 31) & ~31) * ROWB * 2 > 160 * 1024) return SETOK_EUNSUPPORTED;
     const int nq = (T + 31) >> 5;
-    if (nq >= 9) return launch<9>(s, qkv, out, n_imgs, T, H, scale);
+    // T = 257 (ViT-L/14-224): 8 waves x 32 rows + the class-token row as a second pass of wave 0.  8-wave workgroups
+    // fit two per CU (16 waves at 125 VGPRs), 9-wave ones only one: measured 202 vs 242 us per layer.  (Splitting the
+    // class-token tile's keys across the 8 waves and merging partial softmaxes through LDS was tried: no gain — the
+    // kernel is bound by aggregate VALU/LDS issue, not by the longest wave.)
+    if (nq >= 9) return launch<8>(s, qkv, out, n_imgs, T, H, scale);
     if (nq >= 7) return launch<7>(s, qkv, out, n_imgs, T, H, scale);
     if (nq >= 4) return launch<4>(s, qkv, out, n_imgs, T, H, scale);
     return launch<1>(s, qkv, out, n_imgs, T, H, scale);

@@ -33,7 +33,8 @@ constexpr int LDS_BYTES = 2 * STAGE + 8 * 256;    // + a 256-byte bias row per w
 struct PArgs {
     const bf16* A; const bf16* W; const float* bias; const bf16* res; bf16* C;
     int64_t lda, ldc;
-    int M, N, K, tilesM, tilesN, dbg;
+    int M, N, K, tilesM, tilesN, dbg, stagger;
+    unsigned long long* tim;     // debug: per-block {main-loop, epilogue, wait-at-first-ktile} cycle sums
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -118,6 +119,15 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         if (g.bias) lds_dma4(g.bias + min(n0_ + wn * 64 + lane, g.N - 1), scratch_lds);
     };
 
+    // De-synchronise the workgroups: all tiles take the same time, so without this every CU reaches its
+    // epilogue at the same instant and the 32 MB of C-tile stores of a round hit the fabric as one burst
+    // that no CU can overlap with compute.  A one-off start delay of (hash(block) % 16) * stagger/16 spreads the
+    // epilogues over the tile period for the rest of the launch.
+    if (g.stagger > 0) {
+        const int slots = ((blockIdx.x * 37) & 15) * g.stagger;      // units of one s_sleep(32) ~= 2048 cycles ~= 1 us
+        for (int i = 0; i < slots; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+
     int m0, n0, round = 0;
     if (!tile_of(0, m0, n0)) return;
     set_src(m0, n0);
@@ -140,7 +150,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             }
     };
 
+    unsigned long long t_main = 0, t_epi = 0, t_first = 0, t_bar = 0;
     for (;;) {
+        const unsigned long long ts0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
         f32x16 acc[MI][2];
         auto init_acc = [&]() {
             bias_read();
@@ -158,8 +170,17 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         // tile boundary they are all OLDER than the previous epilogue's NSTORE stores (vmcnt retires in order), so
         // those stores may stay in flight and drain under this tile's MFMAs.
         auto top_wait = [&](bool first) {
-            if (first) { if (pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>(); init_acc(); }
-            else wait_vm<0>();
+            if (first) {
+                const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
+                if (pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>();
+                if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
+                init_acc();
+            }
+            else {
+                const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
+                wait_vm<0>();
+                if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
+            }
         };
 
         // One K-tile: 4 k-steps of {6 ds_read_b128, 8 MFMA}.  The (4 + NT) LDS-DMA loads of the NEXT K-tile are
@@ -183,7 +204,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                     const int r = wm * WR + t * 32 + frow;
                     af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
                 }
-                if (do_load) {
+                if (do_load) {                                // two of the next K-tile's LDS-DMA loads per k-step (measured: 4+4 in
+                                                              // the first two k-steps trades vmcnt wait for a longer barrier wait, -8 %)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[ks] + nk0),
                                                      (__attribute__((address_space(3))) void*)(sb + ks * 8192), 16, 0, 0);
                     if (ks < NT)
@@ -203,7 +225,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 
         for (int kt = 0; kt + 1 < nk; ++kt) {
             top_wait(kt == 0);                                     // this wave's pieces of the current K-tile have landed
-            s_barrier_lgkm();                                      // everyone's have; everyone is done with the other stage
+            { const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
+              s_barrier_lgkm();                                    // everyone's have; everyone is done with the other stage
+              if (g.tim) t_bar += __builtin_amdgcn_s_memtime() - w0; }
             multiply((cnt + 1) & 1, (kt + 1) * TK, true);
         }
         // ---- last K-tile of this tile: the NEXT tile's first K-tile, the bias and the first residual rows are
@@ -232,6 +256,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             }
         };
         multiply((cnt + 1) & 1, 0, has_next);
+        const unsigned long long ts1 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
         load_residual(0);
         const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N) && !(g.dbg & 1);
 
@@ -253,16 +278,14 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[i][j][q4 * 4 + e];
-                            if (ACT == SETOK_ACT_QUICK_GELU) x = x / (1.0f + __expf(-1.702f * x));
+                            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
                             else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
                             v[e] = (bf16)x;
                         }
                         const int row = ii * 32 + frow;
                         *reinterpret_cast<bf16x4*>(stg + row * 128 + (((j * 4 + q4) ^ (row & 7)) << 4) + 8 * hi) = v;
                     }
-            // the NEXT pass's residual rows are requested before this pass's stores, so waiting for them later
-            // never waits for these (younger, in-order) stores
-            if (h + 1 < HALVES) load_residual(h + 1);
+            if (h + 1 < HALVES) load_residual(h + 1);            // requested before this pass's stores (vmcnt retires in order)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave re-reads only its own staging rows
             constexpr int CH = NLD >= 4 ? NLD / 2 : NLD;           // two chunks keep the register footprint low
 #pragma unroll
@@ -287,10 +310,12 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                 }
             }
         }
+        if (g.tim) { const unsigned long long ts2 = __builtin_amdgcn_s_memtime(); t_main += ts1 - ts0; t_epi += ts2 - ts1; }
         if (!has_next) break;
         pend = interior ? NSTORE : -1;
         m0 = nm0; n0 = nn0; ++round;
     }
+    if (g.tim && tid == 0) { g.tim[blockIdx.x * 4 + 0] = t_main; g.tim[blockIdx.x * 4 + 1] = t_epi; g.tim[blockIdx.x * 4 + 2] = t_first; g.tim[blockIdx.x * 4 + 3] = ((unsigned long long)(round + 1) << 40) | t_bar; }
 }
 
 template <int NT>
@@ -337,11 +362,25 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int tm_main = tilesM - p;
     static const int dbg = [] { const char* e = getenv("SETOK_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     if (dbg & 4) p = 0;
-    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg};
+    static const int stg = [] { const char* e = getenv("SETOK_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
+    static unsigned long long* tim = nullptr;
+    if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
+    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, stg, timing ? tim : nullptr};
     int rc = launch_nt<4>(s, g, act, ncu);
+    if (timing && tim) {
+        unsigned long long h[256 * 4];
+        if (hipMemcpy(h, tim, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            double a = 0, b = 0, c = 0, r = 0; int nb = ncu < tilesN * (tilesM - p) ? ncu : tilesN * (tilesM - p);
+            double bar = 0;
+            for (int i = 0; i < nb; ++i) { a += h[i * 4]; b += h[i * 4 + 1]; c += h[i * 4 + 2]; r += (double)(h[i * 4 + 3] >> 40); bar += (double)(h[i * 4 + 3] & ((1ull << 40) - 1)); }
+            fprintf(stderr, "[gemm timing] M=%d N=%d K=%d tiles/block=%.2f  per tile: main %.0f cyc (vmcnt waits %.0f, barrier waits %.0f), epilogue %.0f cyc\n",
+                    M, N, K, r / nb, a / r, c / r, bar / r, b / r);
+        }
+    }
     if (rc != SETOK_OK || p == 0) return rc;
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
-            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TM), cdiv(N, 64), dbg};
+            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TM), cdiv(N, 64), dbg, 0, nullptr};
     return launch_nt<1>(s, t, act, ncu);
 }
