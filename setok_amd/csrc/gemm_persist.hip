@@ -318,6 +318,140 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     if (g.tim && tid == 0) { g.tim[blockIdx.x * 4 + 0] = t_main; g.tim[blockIdx.x * 4 + 1] = t_epi; g.tim[blockIdx.x * 4 + 2] = t_first; g.tim[blockIdx.x * 4 + 3] = ((unsigned long long)(round + 1) << 40) | t_bar; }
 }
 
+// --------------------------------------------------------------------------------------------
+// Tail kernel: the < 1-round remainder of M (p*256 rows) as 256 x 64 tiles, ONE tile per workgroup.
+// These launches are latency-bound (few workgroups, 16-64 K-tiles each), so the 40 KiB stages are
+// triple-buffered: two K-tiles of operands are in flight while one is multiplied.
+// --------------------------------------------------------------------------------------------
+constexpr int TSTAGE = 40 * 1024;                // A 32 KiB + W 8 KiB
+constexpr int TAIL_LDS = 3 * TSTAGE + 256;       // + bias row
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_tail_kernel(PArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, hi = lane >> 5;
+    const int nk = g.K / TK;
+    const int m0 = (blockIdx.x / g.tilesN) * TM, n0 = (blockIdx.x % g.tilesN) * 64;
+    float* sbias = reinterpret_cast<float*>(smem + 3 * TSTAGE);
+    if (tid < 64) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
+
+    const bf16* a_src[4]; const bf16* b_src;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
+        a_src[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+        if (i == 0) b_src = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
+    }
+    // LDS-DMA through inline asm: with two K-tiles (10 loads per lane) in flight hipcc's waitcnt pass runs out of
+    // tracked LDS-DMA slots (8) and falls back to `s_waitcnt vmcnt(0)` in front of every ds_read, which serialises the
+    // whole pipeline (measured: 2.4 us per K-tile instead of 0.6).  All waits in this loop are the explicit ones below.
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
+    auto dma16 = [&](const bf16* ptr, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(ptr), "s"(lds_dst) : "memory");
+    };
+    auto issue = [&](int stage, int k0, int i) {            // piece i of a K-tile: A chunk i (+ the W chunk with i == 0)
+        const unsigned sb = lds0 + stage * TSTAGE;
+        dma16(a_src[i] + k0, sb + i * 8192);
+        if (i == 0) dma16(b_src + k0, sb + BOFF);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue(0, 0, i);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue(1, TK, i);
+    }
+    f32x16 acc[2];
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vm<5>(); else wait_vm<0>();   // K-tile kt has landed; kt+1 (5 loads per lane) may still fly
+        s_barrier_lgkm();
+        if (kt == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = sbias[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        }
+        const char* Ab = smem + (kt % 3) * TSTAGE;
+        const char* Bb = Ab + BOFF;
+        const bool more = kt + 2 < nk;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 wf[2], af;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = t * 32 + frow;
+                wf[t] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
+            }
+            const int r = wave * 32 + frow;
+            af = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
+            if (more) issue((kt + 2) % 3, (kt + 2) * TK, ks);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af, acc[j], 0, 0, 0);
+        }
+    }
+    // epilogue: 32 rows x 64 columns per wave, staged through stage 0 (every load has landed)
+    const int slot = lane & 7, col = n0 + slot * 8;
+    const bool col_ok = col < g.N;
+    bf16x8 rv[4];
+    if (g.res) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int grow = m0 + wave * 32 + it * 8 + (lane >> 3);
+            if (grow < g.M && col_ok) rv[it] = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
+        }
+    }
+    s_barrier_lgkm();
+    char* stg = smem + wave * (32 * 128);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[j][q4 * 4 + e];
+                if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
+                else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                v[e] = (bf16)x;
+            }
+            *reinterpret_cast<bf16x4*>(stg + frow * 128 + (((j * 4 + q4) ^ (frow & 7)) << 4) + 8 * hi) = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int grow = m0 + wave * 32 + row;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
+        if (grow < g.M && col_ok) {
+            if (g.res) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[it][e]);
+            }
+            *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = v;
+        }
+    }
+}
+
+int launch_tail(hipStream_t s, const PArgs& g, int act) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        bool ok = hipFuncSetAttribute((const void*)gemm_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+        if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int grid = g.tilesM * g.tilesN;
+    if (act == SETOK_ACT_NONE) gemm_tail_kernel<0><<<grid, 512, TAIL_LDS, s>>>(g);
+    else if (act == SETOK_ACT_QUICK_GELU) gemm_tail_kernel<1><<<grid, 512, TAIL_LDS, s>>>(g);
+    else gemm_tail_kernel<2><<<grid, 512, TAIL_LDS, s>>>(g);
+    SETOK_CHECK_LAUNCH("setok_linear(tail)");
+    return SETOK_OK;
+}
+
 template <int NT>
 int launch_nt(hipStream_t s, const PArgs& g, int act, int n_cu) {
     static bool attr_set = false;
@@ -382,5 +516,5 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
             lda, ldc, M - m_off, N, K, cdiv(M - m_off, TM), cdiv(N, 64), dbg, 0, nullptr};
-    return launch_nt<1>(s, t, act, ncu);
+    return launch_tail(s, t, act);
 }
