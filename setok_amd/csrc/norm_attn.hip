@@ -79,6 +79,49 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
     const int64_t ld = 3LL * H * Dh;
     const T* qp = qkv + (int64_t)row * ld + h * Dh;
     float buf[V];
+    if (n <= 64 && Dh % (64 * V) == 0) {
+        // Short segments (the clusters of the SeTok head average ~7 tokens, the inter-encoder ~36): all 64 lanes
+        // share every key — each lane owns a V-wide slice of the head dimension, K/V rows are read as coalesced
+        // 16-byte pieces, the dot products are wave reductions, key j's probability lives in lane j.
+        constexpr int MAXC = 2;                                     // head dim up to 2 * 64 * V (1024 for bf16)
+        const int nc = Dh / (64 * V);
+        float qreg[MAXC][V], oreg[MAXC][V];
+        for (int c = 0; c < nc && c < MAXC; ++c) {
+            ld_vec<T>(qp + (c * 64 + lane) * V, qreg[c]);
+#pragma unroll
+            for (int i = 0; i < V; ++i) oreg[c][i] = 0.f;
+        }
+        float sc = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            const T* kp = qkv + (int64_t)(s0 + j) * ld + (int64_t)H * Dh + h * Dh;
+            float acc = 0.f;
+            for (int c = 0; c < nc && c < MAXC; ++c) {
+                ld_vec<T>(kp + (c * 64 + lane) * V, buf);
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc = fmaf(qreg[c][i], buf[i], acc);
+            }
+            acc = wave_sum(acc) * scale;
+            if (lane == j) sc = acc;
+        }
+        const float mxs = wave_max(sc);
+        const float e = (lane < n) ? expf(sc - mxs) : 0.f;
+        const float inv = 1.0f / wave_sum(e);
+        for (int j = 0; j < n; ++j) {
+            const float p = __shfl(e, j, 64);
+            const T* vp = qkv + (int64_t)(s0 + j) * ld + 2LL * H * Dh + h * Dh;
+            for (int c = 0; c < nc && c < MAXC; ++c) {
+                ld_vec<T>(vp + (c * 64 + lane) * V, buf);
+#pragma unroll
+                for (int i = 0; i < V; ++i) oreg[c][i] = fmaf(p, buf[i], oreg[c][i]);
+            }
+        }
+        for (int c = 0; c < nc && c < MAXC; ++c) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) oreg[c][i] *= inv;
+            st_vec<T>(out + (int64_t)row * H * Dh + h * Dh + (c * 64 + lane) * V, oreg[c]);
+        }
+        return;
+    }
     for (int d = lane * V; d < Dh; d += 64 * V) {
         ld_vec<T>(qp + d, buf);
 #pragma unroll

@@ -204,3 +204,34 @@ def test_boundary_errors_and_attributes():
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 6e-2)])
+def test_336_input_576_patches(dt, tol):
+    """cfg4 geometry (336^2 / patch 14 -> T = 577, N = 576 = 24^2) on a shallow tower: exercises the 19-tile
+    attention path (K/V of a head = 152 KiB of LDS), N = 576 clustering and the ragged head."""
+    vc = O.VitConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=336, patch_size=14)
+    hc = O.HeadConfig(hidden_dim=128, token_feat_dim=64, min_cluster_num=16, threshold=0.5, nheads=2, dim_feedforward=256,
+                      mm_vision_select_layer=-1)
+    sd = O.init_tower_weights(vc, 0); sd.update(O.init_head_weights(hc, 1))
+    tok = SetokTokenizer(vision_tower=vars(vc), mm_vision_select_layer=-1, hidden_dim=128, token_feat_dim=64, min_cluster_num=16,
+                         threshold=0.5, nheads=2, dim_feedforward=256)
+    tok.load_state_dict(sd, strict=False)
+    tok = tok.to(device=DEV, dtype=dt).eval()
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(2, 3, 336, 336, generator=g)
+    feats = tok.image_feature_encoder(images.to(DEV)).float().cpu()
+    feats_ref, ref = O.encode(sd, vc, hc, images)
+    assert tuple(feats.shape) == (2, 576, 128)
+    assert _rel(feats, feats_ref) < tol
+    toks, idx, score = tok(images.to(DEV))
+    assert tuple(idx.shape) == (2, 576) and tuple(score.shape) == (2, 1, 576)
+    for i in range(2):
+        assert toks[i].shape == (16, 64)                         # threshold 0.5 -> fallback to min_cluster_num centres
+        if dt == torch.float32:
+            sens = O.cluster_sensitivity(ref[i].x, 16, 0.5, 16, ulps=64.0)
+            if sens["centres_certain"]:
+                same = idx[i].cpu() == ref[i].idx_cluster
+                assert bool((same | ~sens["assign_certain"]).all())
+                if bool(same.all()):
+                    assert _rel(toks[i], ref[i].tokens) < TOL
