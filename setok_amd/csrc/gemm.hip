@@ -23,6 +23,7 @@ struct GemmArgs {
 };
 
 template <typename TO> __device__ inline float ld_out(const TO* p) { return Elem<TO>::ld(p); }
+template <typename TO> __device__ inline float round_to(float v) { return (float)(TO)v; }
 
 // --------------------------------------------------------------------------------------------
 // bf16 128x128x64
@@ -57,13 +58,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         st_off[p] = lds_off_bf16(row, kc);
     }
 
+    // The bias is the accumulators' initial value and the residual is added to the ROUNDED Linear output — exactly
+    // the arithmetic of the persistent kernel (gemm_persist.hip), so a row's result does not depend on which of the
+    // two kernels (i.e. on how many rows the batch has) computed it.
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+        }
 
     uint4 ra[4], rb[4];
     auto load_global = [&](int k0) {
@@ -118,16 +125,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
             if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (g.act == SETOK_ACT_QUICK_GELU) v = FAST_ACT ? v / (1.0f + __expf(-1.702f * v)) : v / (1.0f + expf(-1.702f * v));
+                float v = acc[i][j][r];
+                if (g.act == SETOK_ACT_QUICK_GELU) v = FAST_ACT ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * v)) : v / (1.0f + expf(-1.702f * v));
                 else if (g.act == SETOK_ACT_GELU_ERF) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 const int64_t o = (int64_t)row * g.ldc + col;
-                if (R) v += ld_out<TO>(R + o);
+                if (R) v = round_to<TO>(v) + ld_out<TO>(R + o);           // Linear output rounded to TO first (no-op for fp32)
                 Elem<TO>::st(C + o, v);
             }
         }

@@ -235,3 +235,33 @@ def test_336_input_576_patches(dt, tol):
                 assert bool((same | ~sens["assign_certain"]).all())
                 if bool(same.all()):
                     assert _rel(toks[i], ref[i].tokens) < TOL
+
+
+def test_full_size_batch_invariance_and_properties():
+    """BASELINE cfg2 at full size (B = 256, ViT-L/14-224, bf16, dyn-k): size-independent properties.
+    Images are independent units and every kernel's arithmetic per output row is independent of the
+    other rows, so an image's result must be BIT-IDENTICAL whether it is encoded in the batch of 256 or in a batch of 3;
+    plus determinism and the structural invariants of the clustering."""
+    from setok_amd.synthetic import init_synthetic_
+    tok = SetokTokenizer(vision_tower=vars(O.VitConfig()), hidden_dim=1024, token_feat_dim=4096, min_cluster_num=64,
+                         threshold=0.125, nheads=2, dim_feedforward=4096)
+    init_synthetic_(tok, 0, 1)
+    tok = tok.to(device=DEV, dtype=torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(11)
+    images = torch.randn(256, 3, 224, 224, generator=g).to(DEV, torch.bfloat16)
+    toks, idx, score = tok(images)
+    toks2, idx2, score2 = tok(images)
+    assert torch.equal(toks.packed, toks2.packed) and torch.equal(idx, idx2) and torch.equal(score, score2)      # deterministic
+    counts = torch.tensor(toks.counts)
+    assert len(toks) == 256 and int(counts.sum()) == toks.packed.shape[0] and toks.packed.shape[1] == 4096
+    assert int(counts.min()) >= 1 and int(counts.max()) <= 256 and counts.float().std() > 0                      # dyn-k fires
+    assert bool(torch.isfinite(toks.packed.float()).all())
+    lab_max = idx.max(dim=1).values.cpu() + 1
+    assert torch.equal(lab_max, counts)                                                                            # labels cover [0, L_i)
+    for i in (0, 100, 255):
+        assert torch.unique(idx[i]).numel() == toks.counts[i]
+    pick = [5, 131, 255]
+    sub_t, sub_i, sub_s = tok(images[pick])
+    for j, i in enumerate(pick):
+        assert torch.equal(sub_i[j], idx[i]) and torch.equal(sub_s[j], score[i])
+        assert torch.equal(sub_t[j], toks[i])
