@@ -40,17 +40,27 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     const int64_t ld = 3LL * C;
     const bf16* base = qkv + (int64_t)b * T * ld + h * DH;
 
-    // ---- stage K (swizzled) and V (row-major) of this head in LDS; zero the padding rows ----------
-    for (int idx = tid; idx < Tp * 8; idx += NW * 64) {
-        const int key = idx >> 3, c = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < T) {
-            const bf16* p = base + (int64_t)key * ld + c * 8;
-            kv = *reinterpret_cast<const uint4*>(p + C);
-            vv = *reinterpret_cast<const uint4*>(p + 2 * C);
+    // ---- stage K (swizzled) and V (row-major) of this head in LDS by LDS-DMA: every 16-byte piece of the head's
+    //      K and V (2 x Tp x 8 pieces) is requested up front, so the workgroup pays ONE memory round trip instead of one
+    //      per loop iteration of a load->ds_write loop (measured: staging 13.5 k -> cycles per workgroup).  The LDS image is
+    //      lane-linear, so K's slot swizzle is applied to the source address; padding rows re-read row T-1 (finite
+    //      values; their scores are masked to -inf and their probabilities are exactly 0).
+    {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const int npieces = Tp * 8;                                  // 16-byte pieces per operand; Tp*8 is a multiple of 64
+        for (int p0 = wave_u * 64; p0 < npieces; p0 += NW * 64) {    // this wave's 64 consecutive pieces
+            const int p = p0 + lane, key = p >> 3, c = p & 7;
+            const bf16* src = base + (int64_t)min(key, T - 1) * ld;
+            const bf16* ksrc = src + C + ((c ^ (key & 7)) << 3);     // physical slot c of row `key` holds logical chunk c ^ (key & 7)
+            const bf16* vsrc = src + 2 * C + (c << 3);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(ksrc), "s"(lds0 + p0 * 16) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(vsrc), "s"(lds0 + Tp * ROWB + p0 * 16) : "memory");
         }
-        *reinterpret_cast<uint4*>(Ks + key * ROWB + ((c ^ (key & 7)) << 4)) = kv;
-        *reinterpret_cast<uint4*>(Vs + key * ROWB + (c << 4)) = vv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
@@ -61,6 +71,9 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     const int tr_row = (i16 >> 2) + 4 * (g16 >> 1);            // + 4*hi
     const int tr_col = (g16 & 1) * 16 + (i16 & 3) * 4;         // column of this lane's 8-byte piece
 
+    // (The class-token tile — T = 32k + 1 — costs wave 0 a second pass.  Splitting that tile's keys across the waves and
+    // merging partial softmaxes through LDS was tried twice: no gain, the kernel is bound by the total number of
+    // (q-tile, kv-tile) units per SIMD, and the second workgroup on the CU fills the idle waves' issue slots.)
     for (int qt = wave; qt < nq; qt += NW) {
         const int q = qt * 32 + qi;
         const bf16* qp = base + (int64_t)min(q, T - 1) * ld + hi * 8;
