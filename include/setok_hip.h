@@ -75,6 +75,20 @@ int setok_activation(void* stream, int dtype, const void* x, void* y, int64_t n,
 int setok_attention(void* stream, int dtype, const void* qkv, const int32_t* seg_offsets, int n_segs,
                     int seg_len, void* out, int rows, int H, int Dh, float scale);
 
+/* Multi-head CROSS-attention of uniform query groups to ragged key/value segments — the Q-Former of the
+ * reconstruction decoder (cfg 3): BertSelfAttention.forward's cross branch, module.py:283-286 (keys / values from the
+ * encoder states), :303 (q k^T), :342 (/ sqrt(d_h), passed as `scale`), :343-345 (+ mask), :348 (softmax), :360-364.
+ * The reference pads every image's L_i tokens to a common L and adds (1 - m) * -10000 (module.py:849, 962-973); exp of a
+ * score lowered by 10000 is exactly 0 in fp32, so attending to the UNPADDED segment is the same arithmetic.
+ * q:   (n_segs * q_len, >= H*Dh) rows, stride ldq; query row r belongs to segment r / q_len.
+ * k,v: rows of stride ldkv (typically two column windows of one fused [k | v] projection buffer);
+ *      segment s owns rows [kv_offsets[s], kv_offsets[s+1]), at most max_kv of them (int32[n_segs+1], device);
+ *      kv_offsets == NULL means uniform segments of max_kv rows.
+ * out: (n_segs * q_len, H*Dh) rows of stride ldo. */
+int setok_cross_attention(void* stream, int dtype, const void* q, int64_t ldq, const void* k, const void* v,
+                          int64_t ldkv, const int32_t* kv_offsets, int n_segs, int q_len, int max_kv, void* out,
+                          int64_t ldo, int H, int Dh, float scale);
+
 /* ---- ViT tower glue (HF CLIPVisionEmbeddings reached from clip_encoder.py:59) ------------ */
 
 /* im2col for the stride-p patch conv: images (B,3,H,W) -> patches (B*g*g, Kpad) with column index

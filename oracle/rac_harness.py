@@ -179,3 +179,48 @@ def rac_forward(tok, images: torch.Tensor, k=None, threshold=None, noise=None, r
         outs.append(rac_head_single(tok, feats[i], k=k, threshold=threshold, noise=nz,
                                     return_stages=return_stages))
     return feats, outs
+
+
+# ----------------------------------------------------------------------------------------------
+# a9 — the Q-Former of the reconstruction decoder.  `BertModel` itself does not construct on the installed
+# transformers (init_weights -> all_tied_weights_keys) and `SetokDeTokenizer` needs timm, diffusers
+# and a network fetch of bert-base-uncased (detokenizer.py:6,10,80), so the reference arithmetic that CAN run here is
+# `BertEmbeddings` + `BertEncoder` (module.py:151-206, 586-690), driven exactly as BertModel.forward drives them
+# (module.py:913-998: query_embeds only, all-ones self mask, inverted encoder mask).
+# ----------------------------------------------------------------------------------------------
+def build_reference_qformer(*, hidden: int, heads: int, intermediate: int, layers: int, cross_freq: int,
+                            encoder_width: int, num_queries: int, eps: float = 1e-12):
+    from transformers.models.bert import BertConfig
+    _, module = load_reference()
+    cfg = BertConfig(hidden_size=hidden, num_attention_heads=heads, intermediate_size=intermediate,
+                     num_hidden_layers=layers, layer_norm_eps=eps)
+    cfg.encoder_width = encoder_width            # detokenizer.py:82
+    cfg.add_cross_attention = True               # :84
+    cfg.cross_attention_freq = cross_freq        # :86
+    cfg.query_length = num_queries               # :87
+    emb = module.BertEmbeddings(cfg).eval()
+    enc = module.BertEncoder(cfg).eval()
+    for layer in enc.layer:                      # detokenizer.py:94-96
+        layer.output = None
+        layer.intermediate = None
+    return emb, enc
+
+
+@torch.no_grad()
+def rac_qformer(emb, enc, sd, query_embeds: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                encoder_attention_mask: torch.Tensor | None, prefix: str = "mapper."):
+    """Load `sd`'s `mapper.*` entries into the reference modules and run BertModel.forward's data path."""
+    esd = {k[len(prefix + "embeddings."):]: v for k, v in sd.items() if k.startswith(prefix + "embeddings.")}
+    missing = emb.load_state_dict(esd, strict=False)
+    assert not missing.unexpected_keys, missing
+    lsd = {k[len(prefix + "encoder."):]: v for k, v in sd.items() if k.startswith(prefix + "encoder.")}
+    res = enc.load_state_dict(lsd, strict=True)
+    B, Q, _ = query_embeds.shape
+    x = emb(query_embeds=query_embeds)                                           # module.py:913-918
+    ext = (1.0 - torch.ones(B, Q))[:, None, None, :] * -10000.0                  # :923-939, 848-849
+    if encoder_attention_mask is None:
+        encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2])     # :967-968
+    enc_ext = (1.0 - encoder_attention_mask.to(x.dtype))[:, None, None, :] * -10000.0   # invert_attention_mask
+    out = enc(x, attention_mask=ext, head_mask=[None] * len(enc.layer), encoder_hidden_states=encoder_hidden_states,
+              encoder_attention_mask=enc_ext, return_dict=True, query_length=Q)   # :984-996
+    return out.last_hidden_state

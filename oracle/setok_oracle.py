@@ -144,7 +144,7 @@ def tower_forward(sd: Dict[str, Tensor], cfg: VitConfig, images: Tensor, select_
 # ----------------------------------------------------------------------------------------------
 # a2 — PositionalEncoding2D (module.py:105-146, utils.py:5-10)
 # ----------------------------------------------------------------------------------------------
-def pos_encoding_2d(h: int, w: int, C: int, dtype=torch.float32) -> Tensor:
+def pos_encoding_2d(h: int, w: int, C: int, dtype=torch.float32, crop: Optional[int] = None) -> Tensor:
     """(h*w, C) table: channels [0,ch) encode the row index, [ch,2ch) the column index, each as
     interleaved (sin, cos) of pos * inv_freq; cropped to C (module.py:112-145)."""
     ch = int(math.ceil(C / 4) * 2)                                                  # module.py:112
@@ -155,7 +155,10 @@ def pos_encoding_2d(h: int, w: int, C: int, dtype=torch.float32) -> Tensor:
     emb = torch.zeros((h, w, ch * 2), dtype=dtype)                                  # :137-141
     emb[:, :, :ch] = emb1d(h).unsqueeze(1).to(dtype)                                # :142 (row index)
     emb[:, :, ch:2 * ch] = emb1d(w).to(dtype)                                       # :143 (col index)
-    return emb[:, :, :C].reshape(h * w, C)                                          # :145
+    crop = C if crop is None else crop              # :126,145: cropped to the INPUT's channel count (== C for the tokenizer)
+    if crop > 2 * ch:
+        raise ValueError("input wider than the positional table (the reference's add would fail to broadcast)")
+    return emb[:, :, :crop].reshape(h * w, crop)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -401,6 +404,172 @@ def encode_images(sd, psd, projector_type, vc: VitConfig, hc: HeadConfig, images
     (L_i, D) after mm_in_projector."""
     _, res = encode(sd, vc, hc, images, k, threshold, noise)
     return [projector_forward(psd, projector_type, r.tokens) for r in res]
+
+
+# ----------------------------------------------------------------------------------------------
+# a9 — reconstruction decoder (cfg 3): SetokDeTokenizer (detokenizer.py:14-120)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class DetokConfig:
+    """Constructor arguments of SetokDeTokenizer (detokenizer.py:15-30) plus the BertConfig fields the
+    Q-Former arithmetic reads (bert-base-uncased values: detokenizer.py:80; they are BertConfig()'s
+    defaults).  `hidden_dim` must equal `mapper_hidden`: the queries (1, Q, hidden_dim) go straight
+    into BertEmbeddings.LayerNorm(hidden_size) (module.py:163,203) — train_setokim.py:361 sets 768."""
+    token_feat_dim: int = 4096
+    hidden_dim: int = 768
+    patch_size: int = 14
+    image_size: int = 256
+    decoder_embed_dim: int = 768
+    decoder_nheads: int = 16
+    decoder_depth: int = 16
+    mlp_ratio: float = 4.0
+    num_hidden_layers: int = 6
+    cross_attention_freq: int = 2
+    mapper_hidden: int = 768
+    mapper_heads: int = 12
+    mapper_intermediate: int = 3072
+    mapper_eps: float = 1e-12
+    norm_eps: float = 1e-5          # norm_layer = nn.LayerNorm (detokenizer.py:25) -> default eps
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size                                   # detokenizer.py:36
+
+    @property
+    def num_queries(self) -> int:
+        return self.grid * self.grid                                                # :37
+
+
+def bert_attention(sd: Dict[str, Tensor], p: str, x: Tensor, kv: Tensor, add_mask: Optional[Tensor],
+                   heads: int, eps: float) -> Tensor:
+    """`BertAttention.forward` (module.py:418-443) in eval mode on x (B, Q, H): BertSelfAttention
+    (:267-373: query from x, key/value from `kv` — x itself for self-attention, the encoder states
+    for cross-attention :283-286 —, scores / sqrt(d_h) :342, + additive mask :343-345, softmax :348,
+    context :360-364) then BertSelfOutput (:383-387: dense, LayerNorm(dense + input))."""
+    B, Q, H = x.shape
+    dh = H // heads
+    def split(t):                                                                   # transpose_for_scores :259-265
+        return t.reshape(t.shape[0], t.shape[1], heads, dh).permute(0, 2, 1, 3)
+    q = split(F.linear(x, sd[p + "self.query.weight"], sd[p + "self.query.bias"]))
+    k = split(F.linear(kv, sd[p + "self.key.weight"], sd[p + "self.key.bias"]))
+    v = split(F.linear(kv, sd[p + "self.value.weight"], sd[p + "self.value.bias"]))
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
+    if add_mask is not None:
+        s = s + add_mask
+    ctx = torch.matmul(torch.softmax(s, dim=-1), v).permute(0, 2, 1, 3).reshape(B, Q, H)
+    y = F.linear(ctx, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    return F.layer_norm(y + x, (H,), sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
+
+
+def qformer_forward(sd: Dict[str, Tensor], dc: DetokConfig, query_embeds: Tensor, enc: Tensor,
+                    enc_mask: Optional[Tensor], prefix: str = "mapper.") -> Tensor:
+    """`BertModel.forward` (module.py:852-1014) as SetokDeTokenizer calls it (detokenizer.py:105-109:
+    query_embeds only, no input_ids, not a decoder).  Embeddings = LayerNorm(query_embeds) (:200-204);
+    the self-attention mask is all ones -> additive 0 (:923-939,849); the encoder mask m becomes
+    (1 - m) * -10000 broadcast over heads and queries (invert_attention_mask, :962-973).
+    Per layer (BertLayer.forward :500-572, query_length == Q): self-attention; cross-attention when
+    layer_num % cross_attention_freq == 0 (:484-491,532-546); then the QUERY feed-forward
+    (intermediate_query: dense + erf-GELU :450-453; output_query: dense, LayerNorm(. + input) :464-468)."""
+    H = dc.mapper_hidden
+    eps = dc.mapper_eps
+    x = F.layer_norm(query_embeds, (H,), sd[prefix + "embeddings.LayerNorm.weight"],
+                     sd[prefix + "embeddings.LayerNorm.bias"], eps)
+    add = None
+    if enc_mask is not None:
+        add = ((1.0 - enc_mask.to(x.dtype)) * -10000.0)[:, None, None, :]
+    zero = torch.zeros((x.shape[0], 1, 1, x.shape[1]), dtype=x.dtype)            # (1 - 1) * -10000
+    for i in range(dc.num_hidden_layers):
+        lp = prefix + f"encoder.layer.{i}."
+        x = bert_attention(sd, lp + "attention.", x, x, zero, dc.mapper_heads, eps)
+        if i % dc.cross_attention_freq == 0:
+            x = bert_attention(sd, lp + "crossattention.", x, enc, add, dc.mapper_heads, eps)
+        y = F.gelu(F.linear(x, sd[lp + "intermediate_query.dense.weight"], sd[lp + "intermediate_query.dense.bias"]))
+        y = F.linear(y, sd[lp + "output_query.dense.weight"], sd[lp + "output_query.dense.bias"])
+        x = F.layer_norm(y + x, (H,), sd[lp + "output_query.LayerNorm.weight"], sd[lp + "output_query.LayerNorm.bias"], eps)
+    return x
+
+
+def vit_block_forward(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int, eps: float) -> Tensor:
+    """timm==0.9.16 `vision_transformer.Block.forward` (third party, pyproject.toml:22, NOT installed here —
+    restated from its published algorithm; call site detokenizer.py:49-51 with qkv_bias=True, no
+    qk_norm, no LayerScale, drop_path 0): x + proj(attn(norm1 x)); x + fc2(gelu(fc1(norm2 x))).
+    Attention: fused qkv Linear -> (3, heads, d_h), scale d_h^-0.5, softmax, proj."""
+    B, T, C = x.shape
+    dh = C // heads
+    y = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(B, T, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = torch.softmax((q * dh ** -0.5) @ k.transpose(-2, -1), dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, T, C)
+    x = x + F.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    y = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+    y = F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def detokenizer_forward(sd: Dict[str, Tensor], dc: DetokConfig, x: Tensor, attention_masks: Optional[Tensor],
+                        return_stages: bool = False):
+    """`SetokDeTokenizer.forward` (detokenizer.py:101-120) on padded tokens x (B, L, token_feat_dim) and
+    mask (B, L).  The reference computes this value and then returns None (defect D5); the restatement
+    returns it: (B, Q, decoder_embed_dim)."""
+    B = x.shape[0]
+    mask_tokens = sd["mask_tokens"].expand(B, -1, -1)                               # :103
+    enc = F.linear(x, sd["mapper_fc_in.weight"], sd["mapper_fc_in.bias"])          # :104
+    mapped = qformer_forward(sd, dc, mask_tokens, enc, attention_masks)             # :105-109
+    y = F.linear(mapped, sd["decoder_fc_in.weight"], sd["decoder_fc_in.bias"])     # :111
+    pos = pos_encoding_2d(dc.grid, dc.grid, dc.hidden_dim, y.dtype, crop=dc.decoder_embed_dim)   # :52,112-114 (module.py:145)
+    y = y + pos[None]                                                               # :115
+    z = y
+    for i in range(dc.decoder_depth):                                               # :117-118
+        z = vit_block_forward(sd, f"pixel_decoder.{i}.", z, dc.decoder_nheads, dc.norm_eps)
+    out = F.layer_norm(z, (dc.decoder_embed_dim,), sd["decoder_norm.weight"], sd["decoder_norm.bias"], dc.norm_eps)  # :120
+    if return_stages:
+        return dict(enc=enc, mapped=mapped, dec_in=y, out=out)
+    return out
+
+
+def init_detok_weights(dc: DetokConfig, seed: int = 3, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Seeded synthetic weights under the reference's state-dict names: xavier-uniform Linear weights /
+    unit LayerNorms for the modules `_init_weights` touches (detokenizer.py:57-69), N(0, 0.02) queries
+    (:39-41) and Q-Former Linears (BertPreTrainedModel._init_weights, initializer_range 0.02).  Biases and
+    LayerNorm affine parameters get small random values so that every term is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    def lin(name, o, i, std=None):
+        if std is None:
+            a = math.sqrt(6.0 / (i + o))
+            sd[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * a
+        else:
+            sd[name + ".weight"] = torch.randn(o, i, generator=g) * std
+        sd[name + ".bias"] = torch.randn(o, generator=g) * 0.02
+    def ln(name, n):
+        sd[name + ".weight"] = 1.0 + 0.05 * torch.randn(n, generator=g)
+        sd[name + ".bias"] = 0.02 * torch.randn(n, generator=g)
+    H, D = dc.mapper_hidden, dc.decoder_embed_dim
+    sd["mask_tokens"] = torch.randn(1, dc.num_queries, dc.hidden_dim, generator=g) * 0.02
+    lin("mapper_fc_in", dc.hidden_dim, dc.token_feat_dim)
+    lin("decoder_fc_in", D, dc.hidden_dim)
+    ln("decoder_norm", D)
+    ln("mapper.embeddings.LayerNorm", H)
+    for i in range(dc.num_hidden_layers):
+        lp = f"mapper.encoder.layer.{i}."
+        atts = ["attention."] + (["crossattention."] if i % dc.cross_attention_freq == 0 else [])
+        for a in atts:
+            kin = dc.hidden_dim if a == "crossattention." else H                    # encoder_width = hidden_dim (detokenizer.py:53,82)
+            lin(lp + a + "self.query", H, H, 0.02)
+            lin(lp + a + "self.key", H, kin, 0.02)
+            lin(lp + a + "self.value", H, kin, 0.02)
+            lin(lp + a + "output.dense", H, H, 0.02)
+            ln(lp + a + "output.LayerNorm", H)
+        lin(lp + "intermediate_query.dense", dc.mapper_intermediate, H, 0.02)
+        lin(lp + "output_query.dense", H, dc.mapper_intermediate, 0.02)
+        ln(lp + "output_query.LayerNorm", H)
+    ff = int(D * dc.mlp_ratio)
+    for i in range(dc.decoder_depth):
+        p = f"pixel_decoder.{i}."
+        ln(p + "norm1", D); lin(p + "attn.qkv", 3 * D, D); lin(p + "attn.proj", D, D)
+        ln(p + "norm2", D); lin(p + "mlp.fc1", ff, D); lin(p + "mlp.fc2", D, ff)
+    return {k: v.to(dtype) for k, v in sd.items()}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ SIGNATURES = {
     "setok_layernorm": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f],
     "setok_activation": [_vp, _i, _vp, _vp, _i64, _i],
     "setok_attention": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f],
+    "setok_cross_attention": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _i, _i, _f],
     "setok_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "setok_vit_assemble": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "setok_select_add_pos": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i],

@@ -1,6 +1,7 @@
 """Factories the LLaVA-derived pipeline calls: `build_vision_tower`
-(src/model/multimodal_encoder/builder.py:6-22) and `build_vision_projector`
-(src/model/multimodal_projector/builder.py:33-64)."""
+(src/model/multimodal_encoder/builder.py:6-22), `build_vision_projector`
+(src/model/multimodal_projector/builder.py:33-64) and `build_vision_generator`
+(src/model/multimodal_generator/builder.py:4-12)."""
 from __future__ import annotations
 
 import re
@@ -10,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .detokenizer import SetokDeTokenizer
 from .tokenizer import SetokTokenizer
 
 
@@ -35,6 +37,17 @@ def build_vision_tower(vision_tower_cfg, **kwargs):
     cfg.pop("vision_tokenizer", None)
     cfg["vision_tower"] = vision_tower
     return SetokTokenizer(**cfg, **kwargs)
+
+
+def build_vision_generator(image_generator_cfg, **kwargs):
+    """multimodal_generator/builder.py:4-12: dataclass / dict / namespace of SetokDeTokenizer ctor kwargs."""
+    if is_dataclass(image_generator_cfg):
+        cfg = asdict(image_generator_cfg)
+    elif isinstance(image_generator_cfg, dict):
+        cfg = dict(image_generator_cfg)
+    else:
+        cfg = dict(vars(image_generator_cfg))
+    return SetokDeTokenizer(**cfg, **kwargs)
 
 
 class IdentityMap(nn.Module):                         # multimodal_projector/builder.py:6-15

@@ -27,18 +27,32 @@ __device__ inline bf16x8 pack8(const float* p) {
     return v;
 }
 
-template <int NW>
+// CROSS = false: self-attention over a fused [q | k | v] buffer, T rows per image (the ViT tower, the Q-Former's
+// query self-attention).  CROSS = true: the Tq query rows of image b (buffer qkv, row stride ldq) attend to the ragged key
+// / value segment [kv_offsets[b], kv_offsets[b+1]) of kptr / vptr (row stride ldkv) — the Q-Former's cross-attention to
+// the image's cluster tokens (module.py:283-286), the additive -10000 mask of the padded reference realised as a segment.
+template <int NW, bool CROSS>
 __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                           int T, int H, float scale_log2e) {
+                                                           int T, int H, float scale_log2e, int64_t ldq,
+                                                           const bf16* __restrict__ kptr, const bf16* __restrict__ vptr,
+                                                           int64_t ldkv, const int32_t* __restrict__ kv_offsets, int Tq_,
+                                                           int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int Tp = (T + 31) & ~31;
-    char* Ks = lds;
-    char* Vs = lds + (size_t)Tp * ROWB;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = H * DH;
-    const int64_t ld = 3LL * C;
-    const bf16* base = qkv + (int64_t)b * T * ld + h * DH;
+    int kv0 = 0;
+    if constexpr (CROSS) { kv0 = kv_offsets[b]; T = min(kv_offsets[b + 1] - kv0, T); }     // T: this image's key count (<= the bound passed in)
+    const int Tp = (T + 31) & ~31;
+    char* Ks = lds;
+    char* Vs = lds + (size_t)Tp * ROWB;
+    const int Tq = CROSS ? Tq_ : T;
+    const int64_t ld = CROSS ? ldq : 3LL * C;                       // query row stride
+    const int64_t ldk = CROSS ? ldkv : 3LL * C;                     // key / value row stride
+    const bf16* base = qkv + (int64_t)b * Tq * ld + h * DH;         // this image's queries
+    const bf16* kbase = CROSS ? kptr + (int64_t)kv0 * ldk + h * DH : base + C;
+    const bf16* vbase = CROSS ? vptr + (int64_t)kv0 * ldk + h * DH : base + 2 * C;
+    if (CROSS && T <= 0) return;
 
     // ---- stage K (swizzled) and V (row-major) of this head in LDS by LDS-DMA: every 16-byte piece of the head's
     //      K and V (2 x Tp x 8 pieces) is requested up front, so the workgroup pays ONE memory round trip instead of one
@@ -51,9 +65,9 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
         const int npieces = Tp * 8;                                  // 16-byte pieces per operand; Tp*8 is a multiple of 64
         for (int p0 = wave_u * 64; p0 < npieces; p0 += NW * 64) {    // this wave's 64 consecutive pieces
             const int p = p0 + lane, key = p >> 3, c = p & 7;
-            const bf16* src = base + (int64_t)min(key, T - 1) * ld;
-            const bf16* ksrc = src + C + ((c ^ (key & 7)) << 3);     // physical slot c of row `key` holds logical chunk c ^ (key & 7)
-            const bf16* vsrc = src + 2 * C + (c << 3);
+            const int64_t roff = (int64_t)min(key, T - 1) * ldk;
+            const bf16* ksrc = kbase + roff + ((c ^ (key & 7)) << 3);   // physical slot c of row `key` holds logical chunk c ^ (key & 7)
+            const bf16* vsrc = vbase + roff + (c << 3);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(ksrc), "s"(lds0 + p0 * 16) : "memory");
@@ -65,7 +79,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     __syncthreads();
 
     const int qi = lane & 31, hi = lane >> 5;
-    const int nq = (T + 31) >> 5, nkv = Tp >> 5;
+    const int nq = (Tq + 31) >> 5, nkv = Tp >> 5;
     // transposing-read address pattern: lanes 4j+p of a 16-lane group supply row j, 4-column piece p
     const int g16 = lane >> 4, i16 = lane & 15;
     const int tr_row = (i16 >> 2) + 4 * (g16 >> 1);            // + 4*hi
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     // (q-tile, kv-tile) units per SIMD, and the second workgroup on the CU fills the idle waves' issue slots.)
     for (int qt = wave; qt < nq; qt += NW) {
         const int q = qt * 32 + qi;
-        const bf16* qp = base + (int64_t)min(q, T - 1) * ld + hi * 8;
+        const bf16* qp = base + (int64_t)min(q, Tq - 1) * ld + hi * 8;
         bf16x8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
@@ -142,8 +156,8 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
-        if (q < T) {
-            bf16* op = out + ((int64_t)b * T + q) * C + h * DH;
+        if (q < Tq) {
+            bf16* op = out + ((int64_t)b * Tq + q) * (CROSS ? ldo : (int64_t)C) + h * DH;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -163,12 +177,30 @@ int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, 
     const size_t smem = (size_t)Tp * ROWB * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
         attr_set = true;
     }
-    attn_vit_kernel<NW><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f);
+    attn_vit_kernel<NW, false><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
+                                                                      0, nullptr, 0, 0);
     SETOK_CHECK_LAUNCH("setok_attention(vit bf16)");
+    return SETOK_OK;
+}
+
+template <int NW>
+int launch_cross(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const bf16* v, int64_t ldkv, const int32_t* kv_offsets,
+                 int n_segs, int q_len, int max_kv, bf16* out, int64_t ldo, int H, float scale) {
+    const int Tp = (max_kv + 31) & ~31;
+    const size_t smem = (size_t)Tp * ROWB * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return setok_fail(SETOK_ELAUNCH, "cross attention: cannot raise dynamic LDS limit");
+        attr_set = true;
+    }
+    attn_vit_kernel<NW, true><<<dim3(H, n_segs), NW * 64, smem, s>>>(q, out, max_kv, H, scale * 1.44269504088896340736f, ldq, k, v, ldkv,
+                                                                     kv_offsets, q_len, ldo);
+    SETOK_CHECK_LAUNCH("setok_cross_attention(bf16 mfma)");
     return SETOK_OK;
 }
 
@@ -185,4 +217,14 @@ int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_im
     if (nq >= 7) return launch<7>(s, qkv, out, n_imgs, T, H, scale);
     if (nq >= 4) return launch<4>(s, qkv, out, n_imgs, T, H, scale);
     return launch<1>(s, qkv, out, n_imgs, T, H, scale);
+}
+
+// Q-Former cross-attention (module.py:283-286,303,342-364): head dim 64, ragged key segments of at most max_kv rows.
+int setok_cross_attention_bf16(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const bf16* v, int64_t ldkv, const int32_t* kv_offsets,
+                               int n_segs, int q_len, int max_kv, bf16* out, int64_t ldo, int H, float scale) {
+    if (!kv_offsets || max_kv < 1 || (size_t)((max_kv + 31) & ~31) * ROWB * 2 > 160 * 1024) return SETOK_EUNSUPPORTED;
+    const int nq = (q_len + 31) >> 5;
+    if (nq >= 8) return launch_cross<8>(s, q, ldq, k, v, ldkv, kv_offsets, n_segs, q_len, max_kv, out, ldo, H, scale);
+    if (nq >= 4) return launch_cross<4>(s, q, ldq, k, v, ldkv, kv_offsets, n_segs, q_len, max_kv, out, ldo, H, scale);
+    return launch_cross<1>(s, q, ldq, k, v, ldkv, kv_offsets, n_segs, q_len, max_kv, out, ldo, H, scale);
 }

@@ -58,8 +58,10 @@ extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const flo
 // segments); the bf16 ViT shape has its own MFMA kernel in attn_vit.hip.
 // --------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ seg_offsets,
-                                                          int n_segs, int seg_len, T* __restrict__ out, int rows, int H,
+__global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ qbase, int64_t ldq, const T* __restrict__ kbase,
+                                                          const T* __restrict__ vbase, int64_t ld,
+                                                          const int32_t* __restrict__ seg_offsets, int n_segs, int seg_len,
+                                                          int q_len, T* __restrict__ out, int64_t ldo, int rows, int H,
                                                           int Dh, float scale) {
     constexpr int V = Elem<T>::VEC;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -67,7 +69,12 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
     float* ps = sm + Dh;            // seg_len (upper bound on the segment length)
     const int row = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     int s0, s1;
-    if (seg_offsets) {
+    if (q_len > 0) {                                                // cross-attention: query row -> its segment's key rows
+        const int seg = row / q_len;
+        if (seg_offsets) { s0 = seg_offsets[seg]; s1 = seg_offsets[seg + 1]; }
+        else { s0 = seg * seg_len; s1 = s0 + seg_len; }
+        if (s1 - s0 > seg_len) s1 = s0 + seg_len;                   // host contract: seg_len bounds every segment
+    } else if (seg_offsets) {
         int lo = 0, hi = n_segs;                                    // find s with off[s] <= row < off[s+1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_offsets[mid] <= row) lo = mid; else hi = mid; }
         s0 = seg_offsets[lo]; s1 = seg_offsets[lo + 1];
@@ -76,8 +83,10 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
         s0 = (row / seg_len) * seg_len; s1 = min(s0 + seg_len, rows);
     }
     const int n = s1 - s0;
-    const int64_t ld = 3LL * H * Dh;
-    const T* qp = qkv + (int64_t)row * ld + h * Dh;
+    const T* qp = qbase + (int64_t)row * ldq + h * Dh;
+    const T* kh = kbase + h * Dh;
+    const T* vh = vbase + h * Dh;
+    T* orow = out + (int64_t)row * ldo + h * Dh;
     float buf[V];
     if (n <= 64 && Dh % (64 * V) == 0) {
         // Short segments (the clusters of the SeTok head average ~7 tokens, the inter-encoder ~36): all 64 lanes
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
         }
         float sc = -INFINITY;
         for (int j = 0; j < n; ++j) {
-            const T* kp = qkv + (int64_t)(s0 + j) * ld + (int64_t)H * Dh + h * Dh;
+            const T* kp = kh + (int64_t)(s0 + j) * ld;
             float acc = 0.f;
             for (int c = 0; c < nc && c < MAXC; ++c) {
                 ld_vec<T>(kp + (c * 64 + lane) * V, buf);
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
         const float inv = 1.0f / wave_sum(e);
         for (int j = 0; j < n; ++j) {
             const float p = __shfl(e, j, 64);
-            const T* vp = qkv + (int64_t)(s0 + j) * ld + 2LL * H * Dh + h * Dh;
+            const T* vp = vh + (int64_t)(s0 + j) * ld;
             for (int c = 0; c < nc && c < MAXC; ++c) {
                 ld_vec<T>(vp + (c * 64 + lane) * V, buf);
 #pragma unroll
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
         for (int c = 0; c < nc && c < MAXC; ++c) {
 #pragma unroll
             for (int i = 0; i < V; ++i) oreg[c][i] *= inv;
-            st_vec<T>(out + (int64_t)row * H * Dh + h * Dh + (c * 64 + lane) * V, oreg[c]);
+            st_vec<T>(orow + (c * 64 + lane) * V, oreg[c]);
         }
         return;
     }
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
     __syncthreads();
     float mx = -INFINITY;
     for (int j = lane; j < n; j += 64) {
-        const T* kp = qkv + (int64_t)(s0 + j) * ld + (int64_t)H * Dh + h * Dh;
+        const T* kp = kh + (int64_t)(s0 + j) * ld;
         float acc = 0.f;
         for (int d = 0; d < Dh; d += V) {
             ld_vec<T>(kp + d, buf);
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
         float o[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) o[i] = 0.f;
-        const T* vp = qkv + (int64_t)s0 * ld + 2LL * H * Dh + h * Dh + d;
+        const T* vp = vh + (int64_t)s0 * ld + d;
         for (int j = 0; j < n; ++j) {
             ld_vec<T>(vp + (int64_t)j * ld, buf);
             const float p = ps[j];
@@ -160,11 +169,13 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) o[i] *= inv;
-        st_vec<T>(out + (int64_t)row * H * Dh + h * Dh + d, o);
+        st_vec<T>(orow + d, o);
     }
 }
 
 int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, int Dh, float scale);  // attn_vit.hip
+int setok_cross_attention_bf16(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const bf16* v, int64_t ldkv, const int32_t* kv_offsets,
+                               int n_segs, int q_len, int max_kv, bf16* out, int64_t ldo, int H, float scale);           // attn_vit.hip
 
 extern "C" int setok_attention(void* stream, int dtype, const void* qkv, const int32_t* seg_offsets, int n_segs,
                                int seg_len, void* out, int rows, int H, int Dh, float scale) {
@@ -181,11 +192,44 @@ extern "C" int setok_attention(void* stream, int dtype, const void* qkv, const i
     const size_t smem = (size_t)(Dh + seg_len) * sizeof(float);
     SETOK_CHECK_ARG(smem <= 64 * 1024, "setok_attention: Dh + seg_len too large for the generic kernel");
     dim3 grid(rows, H);
-    if (dtype == SETOK_BF16)
-        attn_generic_kernel<bf16><<<grid, 64, smem, s>>>((const bf16*)qkv, seg_offsets, n_segs, seg_len, (bf16*)out, rows, H, Dh, scale);
-    else if (dtype == SETOK_F32)
-        attn_generic_kernel<float><<<grid, 64, smem, s>>>((const float*)qkv, seg_offsets, n_segs, seg_len, (float*)out, rows, H, Dh, scale);
-    else return setok_fail(SETOK_EINVAL, "setok_attention: bad dtype %d", dtype);
+    const int64_t C = (int64_t)H * Dh;
+    if (dtype == SETOK_BF16) {
+        const bf16* p = (const bf16*)qkv;
+        attn_generic_kernel<bf16><<<grid, 64, smem, s>>>(p, 3 * C, p + C, p + 2 * C, 3 * C, seg_offsets, n_segs, seg_len, 0, (bf16*)out, C, rows, H, Dh, scale);
+    } else if (dtype == SETOK_F32) {
+        const float* p = (const float*)qkv;
+        attn_generic_kernel<float><<<grid, 64, smem, s>>>(p, 3 * C, p + C, p + 2 * C, 3 * C, seg_offsets, n_segs, seg_len, 0, (float*)out, C, rows, H, Dh, scale);
+    } else return setok_fail(SETOK_EINVAL, "setok_attention: bad dtype %d", dtype);
     SETOK_CHECK_LAUNCH("setok_attention");
+    return SETOK_OK;
+}
+
+extern "C" int setok_cross_attention(void* stream, int dtype, const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                     const int32_t* kv_offsets, int n_segs, int q_len, int max_kv, void* out, int64_t ldo,
+                                     int H, int Dh, float scale) {
+    SETOK_CHECK_ARG(q && k && v && out, "setok_cross_attention: null operand");
+    SETOK_CHECK_ARG(H > 0 && Dh > 0 && Dh % 8 == 0, "setok_cross_attention: bad H=%d Dh=%d", H, Dh);
+    SETOK_CHECK_ARG(n_segs >= 0 && q_len > 0 && max_kv > 0, "setok_cross_attention: bad n_segs=%d q_len=%d max_kv=%d", n_segs, q_len, max_kv);
+    SETOK_CHECK_ARG(ldq >= (int64_t)H * Dh && ldkv >= (int64_t)H * Dh && ldo >= (int64_t)H * Dh && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0,
+                    "setok_cross_attention: bad leading dimensions");
+    if (n_segs == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16 && Dh == 64) {
+        const int rc = setok_cross_attention_bf16(s, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, kv_offsets, n_segs, q_len,
+                                                  max_kv, (bf16*)out, ldo, H, scale);
+        if (rc != SETOK_EUNSUPPORTED) return rc;
+    }
+    const size_t smem = (size_t)(Dh + max_kv) * sizeof(float);
+    SETOK_CHECK_ARG(smem <= 64 * 1024, "setok_cross_attention: Dh + max_kv too large for the generic kernel");
+    const int rows = n_segs * q_len;
+    dim3 grid(rows, H);
+    if (dtype == SETOK_BF16)
+        attn_generic_kernel<bf16><<<grid, 64, smem, s>>>((const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, ldkv, kv_offsets, n_segs, max_kv,
+                                                         q_len, (bf16*)out, ldo, rows, H, Dh, scale);
+    else if (dtype == SETOK_F32)
+        attn_generic_kernel<float><<<grid, 64, smem, s>>>((const float*)q, ldq, (const float*)k, (const float*)v, ldkv, kv_offsets, n_segs,
+                                                          max_kv, q_len, (float*)out, ldo, rows, H, Dh, scale);
+    else return setok_fail(SETOK_EINVAL, "setok_cross_attention: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_cross_attention");
     return SETOK_OK;
 }

@@ -1,0 +1,377 @@
+"""SetokDeTokenizer — MI355X-native counterpart of the reference's reconstruction decoder
+(src/model/setok/detokenizer.py:14-120; BASELINE config 3).
+
+    tokens (L_i, token_feat_dim) per image
+      -> mapper_fc_in                                                   detokenizer.py:104
+      -> Q-Former: Q = (image_size // patch_size)^2 learned queries, self-attention every layer, cross-attention
+         to the image's tokens on layers i % cross_attention_freq == 0, query feed-forward, post-LayerNorm residuals
+         (module.py:151-206, 209-373, 376-387, 476-582)                 detokenizer.py:105-109
+      -> decoder_fc_in, + PositionalEncoding2D                          detokenizer.py:111-115
+      -> decoder_depth x ViT block (timm Block: pre-LN, fused qkv, erf-GELU MLP)   :117-118
+      -> decoder_norm                                                   :120
+
+Same constructor kwargs and the same state-dict key names as the reference (`mask_tokens`, `mapper_fc_in.*`,
+`mapper.embeddings.LayerNorm.*`, `mapper.encoder.layer.{i}.{attention,crossattention}.{self.{query,key,value},
+output.{dense,LayerNorm}}.*`, `mapper.encoder.layer.{i}.{intermediate_query,output_query}.*`, `decoder_fc_in.*`,
+`pixel_decoder.{i}.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.*`, `decoder_norm.*`), so a reference checkpoint loads
+unchanged.  Two deliberate differences, both repairs of defects SURVEY.md lists:
+  * the reference's forward computes the result and returns None (D5); this one returns it, (B, Q, decoder_embed_dim);
+  * the reference wants padded tokens (B, L, D) + a mask; the tokenizer's output is ragged (D3).  Both are accepted — a padded
+    batch is packed by its mask first, because adding (1 - m) * -10000 to a score (module.py:849) makes its softmax weight exactly
+    0 in fp32, i.e. masked keys simply do not take part.
+
+Everything runs on the HIP library (GEMMs, LayerNorms, MFMA attention); the layer-0 query self-attention does not depend on
+the image (all images share `mask_tokens`), so it is computed once per call and broadcast.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Any, Dict, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .tokenizer import PositionalEncoding2D, RaggedTokens
+
+# bert-base-uncased's published config.json (detokenizer.py:27,80 fetches it from the hub; there is no network here and the
+# values are BertConfig()'s defaults) — only the fields the Q-Former arithmetic reads.
+BERT_BASE_UNCASED = dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-12,
+                         hidden_act="gelu", initializer_range=0.02)
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers with the reference's module tree (module.py:151-582) — no arithmetic here
+# ----------------------------------------------------------------------------------------------
+class BertEmbeddings(nn.Module):                         # module.py:151-206 (word / position embeddings are set to None, detokenizer.py:92-93)
+    def __init__(self, cfg):
+        super().__init__()
+        self.LayerNorm = nn.LayerNorm(cfg["hidden_size"], eps=cfg["layer_norm_eps"])
+
+
+class BertSelfAttention(nn.Module):                      # module.py:209-235
+    def __init__(self, cfg, is_cross_attention):
+        super().__init__()
+        hs = cfg["hidden_size"]
+        kin = cfg["encoder_width"] if is_cross_attention else hs
+        self.query = nn.Linear(hs, hs)
+        self.key = nn.Linear(kin, hs)
+        self.value = nn.Linear(kin, hs)
+
+
+class BertSelfOutput(nn.Module):                         # module.py:376-387
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg["hidden_size"], cfg["hidden_size"])
+        self.LayerNorm = nn.LayerNorm(cfg["hidden_size"], eps=cfg["layer_norm_eps"])
+
+
+class BertAttention(nn.Module):                          # module.py:390-395
+    def __init__(self, cfg, is_cross_attention=False):
+        super().__init__()
+        self.self = BertSelfAttention(cfg, is_cross_attention)
+        self.output = BertSelfOutput(cfg)
+
+
+class BertIntermediate(nn.Module):                       # module.py:446-453
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg["hidden_size"], cfg["intermediate_size"])
+
+
+class BertOutput(nn.Module):                             # module.py:457-468
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg["intermediate_size"], cfg["hidden_size"])
+        self.LayerNorm = nn.LayerNorm(cfg["hidden_size"], eps=cfg["layer_norm_eps"])
+
+
+class BertLayer(nn.Module):                              # module.py:476-498 (`intermediate` / `output` are set to None, detokenizer.py:94-96)
+    def __init__(self, cfg, layer_num):
+        super().__init__()
+        self.attention = BertAttention(cfg)
+        self.has_cross_attention = layer_num % cfg["cross_attention_freq"] == 0
+        if self.has_cross_attention:
+            self.crossattention = BertAttention(cfg, is_cross_attention=True)
+        self.intermediate_query = BertIntermediate(cfg)
+        self.output_query = BertOutput(cfg)
+
+
+class BertEncoder(nn.Module):                            # module.py:586-592
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(cfg, i) for i in range(cfg["num_hidden_layers"])])
+
+
+class BertModel(nn.Module):
+    """The Q-Former (`self.mapper`, module.py:729-745): parameters under `embeddings.*` and `encoder.layer.{i}.*`."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = dict(cfg)
+        self.embeddings = BertEmbeddings(cfg)
+        self.encoder = BertEncoder(cfg)
+        std = cfg.get("initializer_range", 0.02)         # BertPreTrainedModel._init_weights
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+                nn.init.zeros_(m.bias)
+
+
+class _VitAttention(nn.Module):                          # timm Attention: qkv, proj
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _VitMlp(nn.Module):                                # timm Mlp: fc1, fc2
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class VitBlock(nn.Module):
+    """timm==0.9.16 vision_transformer.Block as detokenizer.py:49-51 builds it (qkv_bias=True, no qk_norm, no LayerScale,
+    no drop_path): parameters `norm1`, `attn.{qkv,proj}`, `norm2`, `mlp.{fc1,fc2}`."""
+
+    def __init__(self, dim, num_heads, mlp_ratio, norm_layer):
+        super().__init__()
+        self.num_heads = num_heads
+        self.norm1 = norm_layer(dim)
+        self.attn = _VitAttention(dim)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _VitMlp(dim, int(dim * mlp_ratio))
+
+
+def _f32(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _resolve_mapper_config(path_or_name: Union[str, Dict[str, Any], None]) -> Dict[str, Any]:
+    """`BertConfig.from_pretrained(feature_mapper_path_or_name)` (detokenizer.py:80) without a network: a dict, a local
+    directory / config.json, or the name 'bert-base-uncased' (its published values)."""
+    cfg = dict(BERT_BASE_UNCASED)
+    if isinstance(path_or_name, dict):
+        cfg.update(path_or_name)
+    elif isinstance(path_or_name, str) and os.path.exists(path_or_name):
+        f = os.path.join(path_or_name, "config.json") if os.path.isdir(path_or_name) else path_or_name
+        with open(f) as fh:
+            cfg.update({k: v for k, v in json.load(fh).items() if k in BERT_BASE_UNCASED})
+    elif path_or_name not in (None, "bert-base-uncased", "google-bert/bert-base-uncased"):
+        raise ValueError(f"feature_mapper_path_or_name={path_or_name!r}: not a local path and no network is available; "
+                         "pass a config dict, a local directory, or 'bert-base-uncased'")
+    if cfg["hidden_act"] != "gelu":
+        raise ValueError("only hidden_act='gelu' (exact erf) is implemented on the HIP path")
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------------
+class SetokDeTokenizer(nn.Module):
+    def __init__(self,
+                 token_feat_dim: Optional[int] = 4096,
+                 hidden_dim: Optional[int] = 4096,
+                 patch_size: Optional[int] = 14,
+                 image_size: Optional[int] = 256,
+                 decoder_embed_dim: Optional[int] = 4096,
+                 decoder_nheads: Optional[int] = 16,
+                 proj_drop: Optional[float] = 0.2,
+                 attn_drop: Optional[float] = 0.2,
+                 decoder_depth: Optional[int] = 16,
+                 norm_layer: nn.Module = nn.LayerNorm,
+                 mlp_ratio: Optional[float] = 4.0,
+                 feature_mapper_path_or_name: Union[str, Dict[str, Any], None] = "bert-base-uncased",
+                 num_hidden_layers: Optional[int] = 6,
+                 cross_attention_freq: Optional[int] = 2,
+                 initializer_range: Optional[float] = 0.02,
+                 **kwargs) -> None:
+        super().__init__()
+        if norm_layer is not nn.LayerNorm:
+            raise ValueError("only nn.LayerNorm is implemented on the HIP path")
+        self.token_feat_dim = token_feat_dim
+        self.patch_size = patch_size
+        self.height = self.weight = image_size // patch_size                       # detokenizer.py:36 (sic: `weight`)
+        self.num_mask_token = self.height * self.weight
+        self.hidden_dim = hidden_dim
+        self.decoder_embed_dim = decoder_embed_dim
+        self.decoder_nheads = decoder_nheads
+
+        cfg = _resolve_mapper_config(feature_mapper_path_or_name)
+        cfg.update(encoder_width=hidden_dim, add_cross_attention=True, cross_attention_freq=cross_attention_freq,
+                   query_length=self.num_mask_token, num_hidden_layers=num_hidden_layers)          # detokenizer.py:82-88
+        if hidden_dim != cfg["hidden_size"]:
+            # the queries (1, Q, hidden_dim) feed BertEmbeddings.LayerNorm(hidden_size) directly (module.py:163,203): the reference
+            # fails there with its own default hidden_dim=4096; train_setokim.py:361 sets 768
+            raise ValueError(f"hidden_dim ({hidden_dim}) must equal the feature mapper's hidden_size ({cfg['hidden_size']})")
+        if cfg["hidden_size"] % cfg["num_attention_heads"] or decoder_embed_dim % decoder_nheads:
+            raise ValueError("hidden sizes must be multiples of their head counts")        # module.py:213-219
+        self.position_embedding = PositionalEncoding2D(hidden_dim)                 # detokenizer.py:52
+        if decoder_embed_dim > self.position_embedding.channels * 2:
+            # module.py:145 crops the table to the input's channel count; a wider input makes the reference's add fail
+            raise ValueError(f"decoder_embed_dim ({decoder_embed_dim}) exceeds the positional table width "
+                             f"({self.position_embedding.channels * 2}) built for hidden_dim={hidden_dim}")
+
+        query_tokens = nn.Parameter(torch.zeros(1, self.num_mask_token, hidden_dim))
+        query_tokens.data.normal_(mean=0.0, std=initializer_range)
+        self.mask_tokens = query_tokens                                            # detokenizer.py:39-41
+        self.mapper_fc_in = nn.Linear(token_feat_dim, hidden_dim)
+        self.decoder_fc_in = nn.Linear(hidden_dim, decoder_embed_dim)
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.pixel_decoder = nn.ModuleList([VitBlock(decoder_embed_dim, decoder_nheads, mlp_ratio, norm_layer)
+                                            for _ in range(decoder_depth)])
+        self.initialize_weights()                                                  # before the mapper exists, as in the reference (:53-54)
+        self.mapper = BertModel(cfg)
+        self._packed: Dict[str, Any] = {}
+
+    # detokenizer.py:56-69
+    def initialize_weights(self):
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1.0)
+
+    def load_model(self):                                                          # detokenizer.py:98-99
+        pass
+
+    @property
+    def dtype(self):
+        return self.mapper_fc_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.mapper_fc_in.weight.device
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    # -- weight packing: fused q|k|v (self) and k|v (cross) projections, fp32 biases / LayerNorm affine ------------------
+    def _pack(self):
+        w = self.mapper_fc_in.weight
+        key = (w.dtype, str(w.device), w._version, self.mask_tokens._version)
+        if self._packed.get("key") == key:
+            return self._packed
+        lin = lambda m: (m.weight.detach().contiguous(), _f32(m.bias))
+        ln = lambda m: (_f32(m.weight), _f32(m.bias), m.eps)
+        cat = lambda *ms: (torch.cat([m.weight.detach() for m in ms], 0).contiguous(), torch.cat([_f32(m.bias) for m in ms], 0))
+        layers = []
+        for lyr in self.mapper.encoder.layer:
+            d = dict(qkv=cat(lyr.attention.self.query, lyr.attention.self.key, lyr.attention.self.value),
+                     so=lin(lyr.attention.output.dense), sln=ln(lyr.attention.output.LayerNorm),
+                     fi=lin(lyr.intermediate_query.dense), fo=lin(lyr.output_query.dense), fln=ln(lyr.output_query.LayerNorm))
+            if lyr.has_cross_attention:
+                c = lyr.crossattention
+                d.update(cq=lin(c.self.query), ckv=cat(c.self.key, c.self.value), co=lin(c.output.dense), cln=ln(c.output.LayerNorm))
+            layers.append(d)
+        blocks = [dict(n1=ln(b.norm1), qkv=lin(b.attn.qkv), proj=lin(b.attn.proj), n2=ln(b.norm2), fc1=lin(b.mlp.fc1),
+                       fc2=lin(b.mlp.fc2)) for b in self.pixel_decoder]
+        self._packed = dict(key=key, fc_in=lin(self.mapper_fc_in), emb_ln=ln(self.mapper.embeddings.LayerNorm), layers=layers,
+                            dec_in=lin(self.decoder_fc_in), blocks=blocks, dec_ln=ln(self.decoder_norm),
+                            queries=self.mask_tokens.detach()[0].contiguous())
+        return self._packed
+
+    # -- stages --------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _qformer(self, pk, enc: torch.Tensor, kv_offsets: torch.Tensor, B: int, max_kv: int) -> torch.Tensor:
+        """BertModel.forward (module.py:852-1014) as detokenizer.py:105-109 calls it, on packed rows.
+        enc: (sum L_i, hidden) mapped tokens; returns (B * Q, hidden)."""
+        cfg = self.mapper.cfg
+        Hh = cfg["num_attention_heads"]
+        hs = cfg["hidden_size"]
+        Dh = hs // Hh
+        scale = 1.0 / math.sqrt(Dh)                                                # module.py:342
+        Q = self.num_mask_token
+        h = ops.layernorm(pk["queries"], *pk["emb_ln"][:2], pk["emb_ln"][2])      # module.py:203; (Q, hs), shared by every image
+        nb = 1                                                                      # images the rows of `h` currently stand for
+        for d in pk["layers"]:
+            # self-attention among the Q queries (module.py:511-519), BertSelfOutput (:383-387)
+            qkv = ops.linear(h, *d["qkv"])
+            o = ops.attention(qkv, Hh, Dh, scale, seg_len=Q)
+            y = ops.linear(o, *d["so"], residual=h)
+            h = ops.layernorm(y, *d["sln"][:2], d["sln"][2], out=y)
+            if "cq" in d:                                                          # module.py:532-546
+                if nb != B:                                                        # first image-dependent step: broadcast the shared rows
+                    h = h.unsqueeze(0).expand(B, Q, hs).reshape(B * Q, hs).contiguous()
+                    nb = B
+                q = ops.linear(h, *d["cq"])
+                kv = ops.linear(enc, *d["ckv"])                                    # (sum L_i, 2 * hs) = [key | value]
+                o = ops.cross_attention(q, kv[:, :hs], kv[:, hs:], Hh, Dh, scale, Q, kv_offsets, B, max_kv)
+                y = ops.linear(o, *d["co"], residual=h)
+                h = ops.layernorm(y, *d["cln"][:2], d["cln"][2], out=y)
+            # query feed-forward (module.py:579-582): dense + erf-GELU, dense, LayerNorm(. + input)
+            u = ops.linear(h, *d["fi"], act=ops.ACT_GELU_ERF)
+            y = ops.linear(u, *d["fo"], residual=h)
+            h = ops.layernorm(y, *d["fln"][:2], d["fln"][2], out=y)
+        if nb != B:                                                                 # no cross-attention layer at all
+            h = h.unsqueeze(0).expand(B, Q, hs).reshape(B * Q, hs).contiguous()
+        return h
+
+    @torch.no_grad()
+    def _pixel_decoder(self, pk, h: torch.Tensor, B: int) -> torch.Tensor:
+        """detokenizer.py:117-120 on rows (B * Q, D): timm Block = x + proj(attn(norm1 x)); x + fc2(gelu(fc1(norm2 x)))."""
+        Q, D, Hh = self.num_mask_token, self.decoder_embed_dim, self.decoder_nheads
+        Dh = D // Hh
+        y = None
+        for b in pk["blocks"]:
+            y = ops.layernorm(h, *b["n1"][:2], b["n1"][2], out=y)
+            qkv = ops.linear(y, *b["qkv"])
+            o = ops.attention(qkv, Hh, Dh, Dh ** -0.5, seg_len=Q)
+            ops.linear(o, *b["proj"], residual=h, out=h)
+            y = ops.layernorm(h, *b["n2"][:2], b["n2"][2], out=y)
+            u = ops.linear(y, *b["fc1"], act=ops.ACT_GELU_ERF)
+            ops.linear(u, *b["fc2"], residual=h, out=h)
+        return ops.layernorm(h, *pk["dec_ln"][:2], pk["dec_ln"][2], out=y)
+
+    @torch.no_grad()
+    def forward(self, x, attention_masks: Optional[torch.Tensor] = None, return_stages: bool = False):
+        """x: RaggedTokens (the tokenizer's output), a list of (L_i, D) tensors, or padded (B, L, D) with
+        `attention_masks` (B, L) (1 = token, 0 = padding; None = all tokens).  Returns (B, Q, decoder_embed_dim)."""
+        if isinstance(x, (list, tuple)):
+            x = RaggedTokens(torch.cat(list(x), 0), [t.shape[0] for t in x])
+        if isinstance(x, RaggedTokens):
+            packed, counts = x.packed, x.counts
+        else:
+            if x.dim() != 3:
+                raise ValueError("expected padded tokens of shape (B, L, token_feat_dim)")
+            B, L, _ = x.shape
+            if attention_masks is None:
+                packed, counts = x.reshape(B * L, -1), [L] * B
+            else:
+                m = attention_masks.to(torch.bool)
+                if m.shape != (B, L):
+                    raise ValueError(f"attention_masks must have shape {(B, L)}, got {tuple(m.shape)}")
+                packed, counts = x[m], m.sum(dim=1).tolist()
+        B = len(counts)
+        if packed.shape[-1] != self.token_feat_dim:
+            raise ValueError(f"token feature dim {packed.shape[-1]} != token_feat_dim {self.token_feat_dim}")
+        if B == 0 or min(counts) < 1:
+            raise ValueError("every image needs at least one token (an all-masked row has no defined softmax on this path)")
+        pk = self._pack()
+        packed = packed.to(self.dtype).contiguous()
+        offs = torch.zeros(B + 1, dtype=torch.int32)
+        offs[1:] = torch.tensor(counts, dtype=torch.int32).cumsum(0)
+        kv_offsets = offs.to(packed.device, non_blocking=True)
+
+        enc = ops.linear(packed, *pk["fc_in"])                                     # detokenizer.py:104
+        mapped = self._qformer(pk, enc, kv_offsets, B, max(counts))                # :105-109
+        dec = ops.linear(mapped, *pk["dec_in"])                                    # :111
+        Q, D = self.num_mask_token, self.decoder_embed_dim
+        pos = self.position_embedding.table(self.height, self.weight, dec.dtype, dec.device, crop=D)   # :112-114, module.py:145
+        dec_in = ops.select_add_pos(dec, pos, B, Q, 0)                             # :115
+        stages = dict(enc=enc, mapped=mapped.reshape(B, Q, -1), dec_in=dec_in.reshape(B, Q, D).clone()) if return_stages else None
+        out = self._pixel_decoder(pk, dec_in, B).reshape(B, Q, D)                  # :117-120
+        if return_stages:
+            stages["out"] = out
+            return stages
+        return out

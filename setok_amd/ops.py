@@ -111,6 +111,24 @@ def attention(qkv: Tensor, H: int, Dh: int, scale: float, seg_len: int, seg_offs
     return out
 
 
+def cross_attention(q: Tensor, k: Tensor, v: Tensor, H: int, Dh: int, scale: float, q_len: int, kv_offsets: Optional[Tensor],
+                    n_segs: int, max_kv: int, out: Optional[Tensor] = None) -> Tensor:
+    """Cross-attention of `n_segs` groups of `q_len` query rows to ragged key / value segments (`kv_offsets`: int32
+    device tensor of n_segs + 1 row offsets into k / v; None = uniform segments of `max_kv` rows).  q, k, v are 2-D row views
+    (column windows of wider buffers are fine: only the row stride is passed down)."""
+    assert q.dim() == 2 and k.dim() == 2 and v.dim() == 2 and q.shape[1] == H * Dh and k.shape[1] == H * Dh and v.shape[1] == H * Dh
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and k.stride(0) == v.stride(0) and k.dtype == q.dtype == v.dtype
+    assert q.shape[0] == n_segs * q_len
+    if out is None:
+        out = torch.empty((q.shape[0], H * Dh), dtype=q.dtype, device=q.device)
+    if kv_offsets is not None:
+        assert kv_offsets.dtype == torch.int32 and kv_offsets.numel() >= n_segs + 1
+    assert q.is_cuda and k.is_cuda and v.is_cuda
+    _lib.call("setok_cross_attention", _stream(), _code(q.dtype), q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), _p(kv_offsets), n_segs,
+              q_len, max_kv, _p(out), out.stride(0), H, Dh, scale)
+    return out
+
+
 def patchify(images: Tensor, p: int, kpad: int) -> Tensor:
     B, Cin, H, W = images.shape
     assert Cin == 3

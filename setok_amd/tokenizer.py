@@ -131,8 +131,13 @@ class PositionalEncoding2D(nn.Module):
         self.register_buffer("inv_freq", inv_freq)
         self._cache: Dict[Any, torch.Tensor] = {}
 
-    def table(self, h: int, w: int, dtype: torch.dtype, device) -> torch.Tensor:
-        key = (h, w, dtype, str(device))
+    def table(self, h: int, w: int, dtype: torch.dtype, device, crop: Optional[int] = None) -> torch.Tensor:
+        """(h*w, crop) table; `crop` = the channel count of the tensor the reference's forward is given (module.py:126,145),
+        by default the width the module was built for."""
+        crop = self.org_channels if crop is None else crop
+        if crop > self.channels * 2:
+            raise ValueError(f"input has {crop} channels but the table built for {self.org_channels} is {self.channels * 2} wide")
+        key = (h, w, dtype, str(device), crop)
         if key not in self._cache:
             inv = self.inv_freq.detach().float().cpu()
 
@@ -142,7 +147,7 @@ class PositionalEncoding2D(nn.Module):
             emb = torch.zeros((h, w, self.channels * 2), dtype=dtype)
             emb[:, :, : self.channels] = emb1d(h).unsqueeze(1).to(dtype)
             emb[:, :, self.channels: 2 * self.channels] = emb1d(w).to(dtype)
-            self._cache[key] = emb[:, :, : self.org_channels].reshape(h * w, self.org_channels).contiguous().to(device)
+            self._cache[key] = emb[:, :, :crop].reshape(h * w, crop).contiguous().to(device)
         return self._cache[key]
 
     def forward(self, tensor):

@@ -184,9 +184,51 @@ def gen_tower_features_vitl():
         out[f"{i}:fb:tokens_rowsum"] = npy(r["tokens"].double().sum(dim=1))
     save("vitl_224", **out)
 
+# ----------------------------------------------------------------------------------------------
+DETOK_CASES = {
+    # name: (DetokConfig kwargs, seed, token counts per image)
+    "small": (dict(token_feat_dim=96, hidden_dim=64, patch_size=14, image_size=70, decoder_embed_dim=64, decoder_nheads=4,
+                   decoder_depth=2, num_hidden_layers=4, cross_attention_freq=2, mapper_hidden=64, mapper_heads=4,
+                   mapper_intermediate=128), 3, [7, 3, 1, 12]),
+    # the Q-Former at bert-base-uncased dims (detokenizer.py:27,80; hidden_dim=768 per train_setokim.py:361), 224^2 / 14 -> 256 queries
+    "bertbase": (dict(token_feat_dim=256, hidden_dim=768, patch_size=14, image_size=224, decoder_embed_dim=768, decoder_nheads=16,
+                      decoder_depth=1, num_hidden_layers=6, cross_attention_freq=2), 5, [37, 24]),
+}
+
+
+def gen_detok():
+    """a9: the reference's Q-Former (BertEmbeddings + BertEncoder, module.py:151-690) on padded tokens + mask, driven as
+    BertModel.forward / SetokDeTokenizer.forward drive it.  Weights regenerate bit-exactly from the seed
+    (oracle.init_detok_weights); stored: config, seed, the padded inputs, the mask, and the REFERENCE's Q-Former output."""
+    arrs = {}
+    for name, (kw, seed, counts) in DETOK_CASES.items():
+        dc = O.DetokConfig(**kw)
+        sd = O.init_detok_weights(dc, seed=seed)
+        g = torch.Generator().manual_seed(100 + seed)
+        B, L = len(counts), max(counts)
+        x = torch.randn(B, L, dc.token_feat_dim, generator=g)
+        mask = torch.zeros(B, L)
+        for i, c in enumerate(counts):
+            mask[i, :c] = 1
+        emb, enc = R.build_reference_qformer(hidden=dc.mapper_hidden, heads=dc.mapper_heads, intermediate=dc.mapper_intermediate,
+                                             layers=dc.num_hidden_layers, cross_freq=dc.cross_attention_freq,
+                                             encoder_width=dc.hidden_dim, num_queries=dc.num_queries, eps=dc.mapper_eps)
+        mapped_in = torch.nn.functional.linear(x, sd["mapper_fc_in.weight"], sd["mapper_fc_in.bias"])    # detokenizer.py:104
+        ref = R.rac_qformer(emb, enc, sd, sd["mask_tokens"].expand(B, -1, -1), mapped_in, mask)
+        arrs[name + ":cfg_keys"] = np.array(list(kw.keys()))
+        arrs[name + ":cfg_vals"] = np.array([float(v) for v in kw.values()])
+        arrs[name + ":seed"] = np.array(seed)
+        arrs[name + ":x"] = npy(x)
+        arrs[name + ":mask"] = npy(mask)
+        arrs[name + ":mapped_ref"] = npy(ref)
+        print(name, "Q-Former reference output", tuple(ref.shape), float(ref.abs().mean()))
+    save("detok", **arrs)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl"]
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok"]
+    if "detok" in which:
+        gen_detok()
     if "head_small" in which:
         gen_head_small()
     if "cluster_full" in which:

@@ -1,0 +1,106 @@
+"""Parity of the reconstruction decoder (BASELINE config 3) on a real MI355X: setok_amd.SetokDeTokenizer,
+through the C ABI, against (i) the REFERENCE's Q-Former output held in tests/golden/detok.npz and (ii) the CPU oracle for the
+stages behind it (the timm pixel decoder is third-party code that is not installed — restated, see oracle).  `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import setok_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from setok_amd import SetokDeTokenizer
+    from setok_amd.tokenizer import RaggedTokens
+
+DEV = "cuda"
+TOL = 1e-4
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "detok.npz"))
+    kw = {str(k): v for k, v in zip(z[name + ":cfg_keys"], z[name + ":cfg_vals"])}
+    kw = {k: (float(v) if k == "mlp_ratio" else int(v)) for k, v in kw.items()}
+    dc = O.DetokConfig(**kw)
+    sd = O.init_detok_weights(dc, seed=int(z[name + ":seed"]))
+    return dc, sd, _t(z[name + ":x"]), _t(z[name + ":mask"]), _t(z[name + ":mapped_ref"])
+
+
+def _build(dc, sd, dtype=torch.float32):
+    det = SetokDeTokenizer(token_feat_dim=dc.token_feat_dim, hidden_dim=dc.hidden_dim, patch_size=dc.patch_size,
+                           image_size=dc.image_size, decoder_embed_dim=dc.decoder_embed_dim, decoder_nheads=dc.decoder_nheads,
+                           decoder_depth=dc.decoder_depth, mlp_ratio=dc.mlp_ratio,
+                           feature_mapper_path_or_name=dict(hidden_size=dc.mapper_hidden, num_attention_heads=dc.mapper_heads,
+                                                            intermediate_size=dc.mapper_intermediate, layer_norm_eps=dc.mapper_eps),
+                           num_hidden_layers=dc.num_hidden_layers, cross_attention_freq=dc.cross_attention_freq)
+    res = det.load_state_dict(sd, strict=False)          # the reference's key names: nothing extra, only the (recomputed) buffer missing
+    assert not res.unexpected_keys and set(res.missing_keys) <= {"position_embedding.inv_freq"}
+    return det.to(device=DEV, dtype=dtype).eval()
+
+
+@pytest.mark.parametrize("name", ["small", "bertbase"])
+def test_detokenizer_fp32_parity(golden_dir, name):
+    dc, sd, x, mask, mapped_ref = _case(golden_dir, name)
+    det = _build(dc, sd)
+    st = det(x.to(DEV), mask.to(DEV), return_stages=True)
+    assert _rel(st["mapped"], mapped_ref) < TOL           # against the REFERENCE's Q-Former (BertEmbeddings + BertEncoder)
+    ora = O.detokenizer_forward(sd, dc, x, mask, return_stages=True)
+    assert _rel(st["dec_in"], ora["dec_in"]) < TOL
+    assert _rel(st["out"], ora["out"]) < TOL
+    assert tuple(st["out"].shape) == (x.shape[0], dc.num_queries, dc.decoder_embed_dim)
+
+
+def test_detokenizer_input_forms(golden_dir):
+    """Padded + mask, RaggedTokens, a list of per-image tensors: identical results (bit-exact — the same kernels run)."""
+    dc, sd, x, mask, _ = _case(golden_dir, "small")
+    det = _build(dc, sd)
+    a = det(x.to(DEV), mask.to(DEV))
+    counts = mask.sum(1).long().tolist()
+    rows = [x[i, :c].to(DEV) for i, c in enumerate(counts)]
+    b = det(RaggedTokens(torch.cat(rows, 0), counts))
+    c = det(rows)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # one image alone == its rows in the batch (no cross-image term anywhere)
+    one = det([rows[2]])
+    assert torch.equal(one[0], a[2])
+    # no mask = all tokens
+    full = det(x.to(DEV))
+    ora = O.detokenizer_forward(sd, dc, x, None)
+    assert _rel(full, ora) < TOL
+
+
+def test_detokenizer_bf16_agreement(golden_dir):
+    dc, sd, x, mask, mapped_ref = _case(golden_dir, "bertbase")
+    det = _build(dc, sd, torch.bfloat16)
+    st = det(x.to(DEV), mask.to(DEV), return_stages=True)
+    assert st["out"].dtype == torch.bfloat16
+    assert _rel(st["mapped"].float(), mapped_ref) < 3e-2  # bf16 throughput mode: documented tolerance, not the parity bar
+    ora = O.detokenizer_forward(sd, dc, x, mask)
+    assert _rel(st["out"].float(), ora) < 5e-2
+
+
+def test_detokenizer_errors():
+    with pytest.raises(ValueError):                       # the reference's own default (hidden_dim=4096 into LayerNorm(768)) cannot run
+        SetokDeTokenizer()
+    with pytest.raises(ValueError):
+        SetokDeTokenizer(hidden_dim=768, decoder_embed_dim=4096)
+    with pytest.raises(ValueError):
+        SetokDeTokenizer(hidden_dim=768, decoder_embed_dim=768, feature_mapper_path_or_name="some/hub-model")
+    det = SetokDeTokenizer(token_feat_dim=32, hidden_dim=64, image_size=28, decoder_embed_dim=64, decoder_nheads=2, decoder_depth=1,
+                           num_hidden_layers=1, feature_mapper_path_or_name=dict(hidden_size=64, num_attention_heads=2,
+                                                                                 intermediate_size=64)).to(DEV)
+    with pytest.raises(ValueError):
+        det(torch.zeros(2, 3, 16, device=DEV))
+    with pytest.raises(ValueError):
+        det(torch.zeros(2, 3, 32, device=DEV), torch.tensor([[1, 1, 0], [0, 0, 0]], device=DEV))

@@ -130,6 +130,57 @@ def test_attention_ragged(dt, tol):
     assert _rel_err(got, ref) < tol
 
 
+def _cross_ref(q, k, v, H, Dh, scale, q_len, offs):
+    """fp64 reference of the padded reference arithmetic: per segment, softmax(q k^T * scale) v over ITS keys."""
+    out = torch.zeros(q.shape[0], H * Dh, dtype=torch.float64)
+    for s in range(len(offs) - 1):
+        qs = q[s * q_len:(s + 1) * q_len].double().reshape(q_len, H, Dh).transpose(0, 1)
+        ks = k[offs[s]:offs[s + 1]].double().reshape(-1, H, Dh).transpose(0, 1)
+        vs = v[offs[s]:offs[s + 1]].double().reshape(-1, H, Dh).transpose(0, 1)
+        a = torch.softmax(qs @ ks.transpose(-1, -2) * scale, -1)
+        out[s * q_len:(s + 1) * q_len] = (a @ vs).transpose(0, 1).reshape(q_len, H * Dh)
+    return out
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("H,Dh,q_len,lens", [(4, 16, 25, [7, 3, 1, 12]), (12, 64, 256, [37, 24, 1, 64, 65]), (12, 64, 324, [40, 33]),
+                                             (2, 64, 5, [130, 2]), (3, 96, 16, [9, 70])])
+def test_cross_attention_ragged(dt, tol, H, Dh, q_len, lens):
+    """setok_cross_attention (module.py:283-286,303,342-364): query groups x ragged key segments, k / v as column windows of one
+    fused buffer; Dh = 64 in bf16 takes the MFMA kernel, everything else the generic one."""
+    offs = np.concatenate([[0], np.cumsum(lens)]).tolist()
+    C = H * Dh
+    q = _rand(len(lens) * q_len, C, seed=21).to(dt)
+    kv = _rand(offs[-1], 2 * C, seed=22).to(dt)
+    ref = _cross_ref(q, kv[:, :C], kv[:, C:], H, Dh, Dh ** -0.5, q_len, offs)
+    kvd = kv.to(DEV)
+    so = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    got = ops.cross_attention(q.to(DEV), kvd[:, :C], kvd[:, C:], H, Dh, Dh ** -0.5, q_len, so, len(lens), max(lens))
+    assert _rel_err(got, ref) < tol
+    # the mask of the padded reference is equivalent: additive -10000 on the padded keys (module.py:849)
+    if dt == torch.float32:
+        L = max(lens)
+        kp = torch.zeros(len(lens), L, 2 * C); add = torch.full((len(lens), 1, 1, L), -10000.0)
+        for s, n in enumerate(lens):
+            kp[s, :n] = kv[offs[s]:offs[s + 1]]; add[s, ..., :n] = 0
+        qs = q.reshape(len(lens), q_len, H, Dh).transpose(1, 2)
+        ks = kp[..., :C].reshape(len(lens), L, H, Dh).transpose(1, 2); vs = kp[..., C:].reshape(len(lens), L, H, Dh).transpose(1, 2)
+        padded = (torch.softmax(qs @ ks.transpose(-1, -2) * Dh ** -0.5 + add, -1) @ vs).transpose(1, 2).reshape(-1, C)
+        assert _rel_err(got, padded) < 1e-5
+
+
+def test_cross_attention_uniform_and_errors():
+    H, Dh, q_len, L, B = 2, 32, 6, 5, 3
+    C = H * Dh
+    q, kv = _rand(B * q_len, C, seed=23), _rand(B * L, 2 * C, seed=24)
+    ref = _cross_ref(q, kv[:, :C], kv[:, C:], H, Dh, 0.3, q_len, [0, 5, 10, 15])
+    kvd = kv.to(DEV)
+    got = ops.cross_attention(q.to(DEV), kvd[:, :C], kvd[:, C:], H, Dh, 0.3, q_len, None, B, L)
+    assert _rel_err(got, ref) < 3e-6
+    with pytest.raises(Exception):
+        ops.cross_attention(q.to(DEV), kvd[:, :C], kvd[:, C:], H, Dh, 0.3, 0, None, B, L)
+
+
 # ---------------------------------------------------------------------------------------------
 # glue
 # ---------------------------------------------------------------------------------------------

@@ -172,3 +172,44 @@ def test_sensitivity_analysis_accepts_reference_outputs(golden_dir):
         if "mcn32" in name:
             assert not sens["centres_certain"]
     assert n_certain == 5
+
+
+# ---- a9: reconstruction decoder (cfg 3) ------------------------------------------------------------------------------
+def _detok_case(golden_dir, name):
+    z = _load(golden_dir, "detok")
+    kw = {str(k): v for k, v in zip(z[name + ":cfg_keys"], z[name + ":cfg_vals"])}
+    kw = {k: (float(v) if k == "mlp_ratio" else int(v)) for k, v in kw.items()}
+    dc = O.DetokConfig(**kw)
+    sd = O.init_detok_weights(dc, seed=int(z[name + ":seed"]))
+    return dc, sd, _t(z[name + ":x"]), _t(z[name + ":mask"]), _t(z[name + ":mapped_ref"])
+
+
+@pytest.mark.parametrize("name", ["small", "bertbase"])
+def test_qformer_matches_reference(golden_dir, name):
+    """The Q-Former restatement against the reference's BertEmbeddings + BertEncoder output (padded tokens + mask)."""
+    dc, sd, x, mask, ref = _detok_case(golden_dir, name)
+    st = O.detokenizer_forward(sd, dc, x, mask, return_stages=True)
+    torch.testing.assert_close(st["mapped"], ref, rtol=1e-5, atol=1e-5)
+    assert tuple(st["out"].shape) == (x.shape[0], dc.num_queries, dc.decoder_embed_dim)
+    assert torch.isfinite(st["out"]).all()
+
+
+def test_detokenizer_padded_equals_ragged(golden_dir):
+    """(1 - m) * -10000 (module.py:849) == leaving the padded keys out: each image alone, unpadded, gives the same rows."""
+    dc, sd, x, mask, _ = _detok_case(golden_dir, "small")
+    full = O.detokenizer_forward(sd, dc, x, mask)
+    for i in range(x.shape[0]):
+        n = int(mask[i].sum())
+        one = O.detokenizer_forward(sd, dc, x[i:i + 1, :n], None)
+        torch.testing.assert_close(one[0], full[i], rtol=1e-5, atol=1e-5)
+    # and padding VALUES are irrelevant
+    x2 = x.clone(); x2[mask == 0] = 123.0
+    torch.testing.assert_close(O.detokenizer_forward(sd, dc, x2, mask), full, rtol=1e-6, atol=1e-6)
+
+
+def test_detokenizer_pos_table_width():
+    dc = O.DetokConfig(token_feat_dim=8, hidden_dim=16, image_size=28, decoder_embed_dim=32, decoder_nheads=2, decoder_depth=1,
+                       num_hidden_layers=1, mapper_hidden=16, mapper_heads=2, mapper_intermediate=32)
+    sd = O.init_detok_weights(dc)
+    with pytest.raises(ValueError):                      # the reference's `x + pos_emb` cannot broadcast 16 -> 32 channels
+        O.detokenizer_forward(sd, dc, torch.randn(1, 3, 8), None)

@@ -77,3 +77,22 @@ def test_reference_defects_still_present(tok):
         tok(torch.randn(2, 3, 112, 112))
     with pytest.raises(ValueError):
         tok.inter_encoder(torch.randn(5, 64))
+
+
+def test_qformer_restatement_vs_reference_live():
+    """a9: oracle.qformer_forward against the reference's BertEmbeddings + BertEncoder (module.py:151-690), live."""
+    dc = O.DetokConfig(token_feat_dim=48, hidden_dim=32, patch_size=14, image_size=42, decoder_embed_dim=32, decoder_nheads=2,
+                       decoder_depth=1, num_hidden_layers=3, cross_attention_freq=2, mapper_hidden=32, mapper_heads=4,
+                       mapper_intermediate=64)
+    sd = O.init_detok_weights(dc, seed=11)
+    emb, enc = R.build_reference_qformer(hidden=32, heads=4, intermediate=64, layers=3, cross_freq=2, encoder_width=32,
+                                         num_queries=dc.num_queries)
+    torch.manual_seed(0)
+    x = torch.randn(3, 6, 32)
+    mask = torch.ones(3, 6); mask[0, 2:] = 0; mask[2, 5:] = 0
+    q = sd["mask_tokens"].expand(3, -1, -1)
+    ref = R.rac_qformer(emb, enc, sd, q, x, mask)
+    got = O.qformer_forward(sd, dc, q, x, mask)
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+    ref_nomask = R.rac_qformer(emb, enc, sd, q, x, None)
+    torch.testing.assert_close(O.qformer_forward(sd, dc, q, x, None), ref_nomask, rtol=1e-6, atol=1e-6)
