@@ -240,7 +240,7 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
         SETOK_CHECK_ARG(K % BK == 0, "setok_linear(bf16): K=%d must be a multiple of %d", K, BK);
         SETOK_CHECK_ARG(lda % 8 == 0, "setok_linear(bf16): lda must be a multiple of 8");
         // big problems (>= 96 tiles of 256x256): persistent direct-to-LDS kernel (gemm_persist.hip)
-        if (out_dtype == SETOK_BF16 && batch == 1 && N % 8 == 0 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 96 && !g_force_small_tiles)
+        if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 96 && !g_force_small_tiles)
             return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
         dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
         if (out_dtype == SETOK_BF16) gemm_bf16_kernel<bf16, true><<<grid, 256, 0, s>>>(g);

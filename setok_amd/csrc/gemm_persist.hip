@@ -3,38 +3,42 @@
 //   C[M,N] = act(A[M,K] · W[N,K]^T + bias) (+ residual, torch-bf16 semantics: the Linear output is rounded
 //   to bf16 first, then the residual is added and the sum rounded again)
 //
-// One workgroup (8 waves, 2 per SIMD) per CU walks output tiles of 256 x (64*NT) columns:
-//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip).  The LDS image is
-//     lane-linear, so the 16-B-slot XOR swizzle (slot ^= row & 7, cdna guide T2) is applied to the
-//     per-lane SOURCE address and to the ds_read_b128 address (rule 21).  Two 64 KiB stages.
-//   * the K-tiles of consecutive output tiles form ONE continuous stream: while the last K-tile of a
-//     tile is multiplied, the first K-tile of the workgroup's NEXT tile is already in flight, so tile
-//     boundaries pay neither a prologue latency nor a pipeline drain.  Barriers are raw s_barrier +
-//     explicit s_waitcnt (a __syncthreads() would drain the in-flight LDS-DMA, cdna guide §5).
-//   * MFMA operands are swapped (A-operand = W fragment, B-operand = activation fragment): a lane then
-//     holds, for ONE output row, 4 consecutive columns per accumulator quad.  The epilogue adds the
-//     bias and applies the activation in registers, stages bf16 through the LDS stage that has just
-//     been consumed (XOR-swizzled 16-B slots), and writes full 128-byte row segments with 16-byte
-//     stores; the residual is fetched with coalesced 16-byte loads issued before the staging pass.
-//   * tile order: the 32 workgroups resident on one XCD (private 4 MiB L2) cover an 8 (M) x 4 (N)
-//     patch of tiles in every round and share operand panels (cdna guide T1).
-//   * NT = 4 (256x256 tiles) is the workhorse; NT = 1 (256x64 tiles, 8 waves stacked along M) finishes
-//     the <1-round remainder of M so that the big launch runs an exact number of rounds (no tail).
+// One workgroup (8 waves, 2 per SIMD) per CU walks output tiles of 256 x 256:
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), every one issued from inline asm so that
+//     no wait in the kernel is the compiler's guess.  The LDS image is lane-linear, so the 16-B-slot XOR swizzle is applied to
+//     the per-lane SOURCE address and to the ds_read_b128 address.  Two 64 KiB stages.
+//   * the K-tiles of consecutive output tiles form ONE continuous stream: while the last K-tile of a tile is multiplied, the
+//     first K-tile of the workgroup's NEXT tile is already in flight, and its second one is requested before the epilogue's
+//     first store, so tile boundaries pay neither a prologue latency nor a pipeline drain.  Barriers are raw s_barrier +
+//     explicit counted s_waitcnt (a __syncthreads() would drain the in-flight LDS-DMA).
+//   * MFMA operands are swapped (A-operand = W fragment, B-operand = activation fragment): a lane then holds, for ONE output
+//     row, 4 consecutive columns per accumulator quad.  The accumulators start at the bias (scalar loads); the epilogue applies
+//     the activation in registers, transposes bf16 through 32 KiB of LDS of its own (XOR-swizzled 16-B slots, one 32-row MFMA
+//     tile per pass) and writes full 128-byte row segments with 16-byte stores; the residual is fetched with coalesced 16-byte
+//     loads one pass ahead.
+//   * tile order: the 32 workgroups resident on one XCD (private 4 MiB L2) cover an 8 (M) x 4 (N) patch of tiles in every
+//     round and share operand panels.
+//   * a second kernel (256 x 64 tiles, 8 waves stacked along M, three 40 KiB stages) finishes the < 1-round remainder of M so
+//     that the big launch runs an exact number of rounds (no tail).
+// The chip is POWER-bound on this kernel (measured with rocm-smi under load: 1.37-1.38 kW of the 1.4 kW cap, sclk 1.95 GHz on
+// random operands vs 2.39 GHz / 0.95 kW on all-zero operands), so removing stall cycles converts only partly into speed: the
+// tile-boundary change above cut 9 % of the cycles per tile and 3 % of the time.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int TM = 256, TK = 64;
 constexpr int STAGE = 64 * 1024;                 // bytes per pipeline stage (A tile at 0, W tile at BOFF)
 constexpr int BOFF = TM * TK * 2;                // 32 KiB
-constexpr int LDS_BYTES = 2 * STAGE + 8 * 256;    // + a 256-byte bias row per wave
 
 struct PArgs {
     const bf16* A; const bf16* W; const float* bias; const bf16* res; bf16* C;
     int64_t lda, ldc;
-    int M, N, K, tilesM, tilesN, dbg, stagger;
+    int M, N, K, tilesM, tilesN, dbg;
     unsigned long long* tim;     // debug: per-block {main-loop, epilogue, wait-at-first-ktile} cycle sums
+    const float* zero_bias;      // 64 zeros: a null bias is scalar-loaded like a real one
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -50,13 +54,25 @@ __device__ inline int swz(int row) { return ((row >> 1) & 1) | (((row >> 4) & 1)
 template <int N_>
 __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int NT, int ACT>
+// --------------------------------------------------------------------------------------------
+// The tile boundary.  On gfx950 stores and loads retire through ONE in-order counter (vmcnt).  An earlier version of this
+// kernel transposed the epilogue through the operand stage it had just consumed and requested the next tile's second K-tile
+// after the stores; s_memtime showed 11 k of 75 k cycles per tile (K = 1024) going to the stores — 3 k of issue and 7 k of
+// `vmcnt` wait for operands queued behind them.  Hence
+//   * the epilogue has its OWN 32 KiB of LDS (8 waves x 32 rows x 128 B), so the stage freed by a tile's last K-tile
+//     receives the NEXT tile's second K-tile BEFORE the first store is issued: at the next tile's start two K-tiles are in
+//     flight ahead of the stores, the first two waits are counted (`vmcnt(NSTORE + 8)`, `vmcnt(NSTORE)`) and the stores drain
+//     under 64 MFMAs per wave;
+//   * to make room the bias row left LDS: it is read with scalar loads (lgkmcnt domain, no vmcnt interaction at all).
+// --------------------------------------------------------------------------------------------
+constexpr int MAIN_LDS = 2 * STAGE + 8 * 4096;   // 163840: all of the CU's LDS
+__device__ float kZeroBias[64];                    // stands in for a null bias (scalar-loaded like a real one)
+
+template <int ACT>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
-    constexpr int WNC = NT, WMC = 8 / NT;         // wave grid (N x M)
-    constexpr int WR = TM / WMC, MI = WR / 32;    // rows per wave, 32-row MFMA tiles per wave
-    constexpr int HALVES = MI >= 2 ? 2 : 1;       // epilogue passes (staging fits ONE 64 KiB stage)
-    constexpr int RP = WR / HALVES;               // rows per wave per pass
-    constexpr int TNB = 64 * NT;                  // block tile width
+    constexpr int WNC = 4, WR = 128, MI = 4, TNB = 256;
+    constexpr int NL = 8;                          // LDS-DMA ops per lane per K-tile
+    constexpr int NSTORE = WR / 8;                 // 16-byte stores per lane per (interior) tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -67,7 +83,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     const int num_tiles = g.tilesM * g.tilesN;
     const int G = gridDim.x;
 
-    // tile id for (round, block): XCD x (= blockIdx % 8) owns 32 consecutive ids per round
+    // tile id for (round, block): XCD x (= blockIdx % 8) owns 32 consecutive ids per round = an 8 (M) x 4 (N) patch
     auto tile_of = [&](int round, int& m0, int& n0) -> bool {
         int L;
         if ((G & 7) == 0) L = round * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
@@ -81,116 +97,70 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         return true;
     };
 
-    const bf16* a_src[4]; const bf16* b_src[NT];
+    const bf16* a_src[4]; const bf16* b_src[4];
     auto set_src = [&](int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
             a_src[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-            if (i < NT) b_src[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
+            b_src[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
         }
     };
-    auto issue_loads = [&](int stage, int k0) {
-        char* sb = smem + stage * STAGE + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sb + i * 8192), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sb + BOFF + i * 8192), 16, 0, 0);
-    };
-
-    const unsigned scratch_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + 2 * STAGE) + wave * 256);
-    auto lds_dma4 = [&](const void* ptr, unsigned lds_dst) {      // 4 bytes per lane -> LDS[lds_dst + 4*lane]
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
+    auto dma16 = [&](const bf16* ptr, unsigned lds_dst) {
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(ptr), "s"(lds_dst) : "memory");
     };
-    // The bias of a tile (this wave's 64 columns) is DMA'd into the wave's 256-byte scratch row one K-tile
-    // before the tile starts and read back with ds_read (lgkmcnt domain).  An ordinary global load whose
-    // result is first used by the tile's first MFMA makes hipcc emit `s_waitcnt vmcnt(0)` there, which
-    // drains the freshly issued operand loads once per tile (seen in the .s).  Inline asm because a 9th
-    // LDS-DMA builtin per iteration exceeds what hipcc's waitcnt pass tracks and also forces vmcnt(0);
-    // an op the compiler does not count can only make ITS waits stricter (vmcnt retires in order).
-    auto bias_issue = [&](int n0_) {
-        if (g.bias) lds_dma4(g.bias + min(n0_ + wn * 64 + lane, g.N - 1), scratch_lds);
+    auto issue_ktile = [&](int stage, int k0) {                      // a whole K-tile at once (tile boundaries only)
+        const unsigned sb = lds0 + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(a_src[i] + k0, sb + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(b_src[i] + k0, sb + BOFF + i * 8192);
     };
-
-    // De-synchronise the workgroups: all tiles take the same time, so without this every CU reaches its
-    // epilogue at the same instant and the 32 MB of C-tile stores of a round hit the fabric as one burst
-    // that no CU can overlap with compute.  A one-off start delay of (hash(block) % 16) * stagger/16 spreads the
-    // epilogues over the tile period for the rest of the launch.
-    if (g.stagger > 0) {
-        const int slots = ((blockIdx.x * 37) & 15) * g.stagger;      // units of one s_sleep(32) ~= 2048 cycles ~= 1 us
-        for (int i = 0; i < slots; ++i) __builtin_amdgcn_s_sleep(32);
-    }
 
     int m0, n0, round = 0;
     if (!tile_of(0, m0, n0)) return;
     set_src(m0, n0);
-    bias_issue(n0);
-    issue_loads(0, 0);
+    issue_ktile(0, 0);
+    issue_ktile(1, TK);
     int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
-    int pend = 0;                                  // stores of the previous epilogue still allowed in flight (-1: unknown)
-    constexpr int NSTORE = (WR / 8);               // 16-byte stores per lane per tile
-
-    // The bias is the accumulators' initial value (fp32, added before the single bf16 rounding).
-    f32x4 bvn[2][4];
-    auto bias_read = [&]() {
-        const char* row = smem + 2 * STAGE + wave * 256;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                bvn[j][q4] = g.bias ? *reinterpret_cast<const f32x4*>(row + (j * 32 + 8 * q4 + 4 * hi) * 4) : z;
-            }
-    };
+    int pend = 0;                                  // NSTORE: the previous epilogue issued exactly NSTORE stores per lane; else unknown (<= NSTORE)
 
     unsigned long long t_main = 0, t_epi = 0, t_first = 0, t_bar = 0;
     for (;;) {
         const unsigned long long ts0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-        f32x16 acc[MI][2];
-        auto init_acc = [&]() {
-            bias_read();
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = bvn[j][r >> 2][r & 3];
-        };
-
         int nm0 = 0, nn0 = 0;
         const bool has_next = tile_of(round + 1, nm0, nn0);
-        // Operand loads of the current K-tile (and, on a tile's first K-tile, its bias row) have landed.  Across a
-        // tile boundary they are all OLDER than the previous epilogue's NSTORE stores (vmcnt retires in order), so
-        // those stores may stay in flight and drain under this tile's MFMAs.
-        auto top_wait = [&](bool first) {
-            if (first) {
-                const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-                if (pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>();
-                if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
-                init_acc();
-            }
-            else {
-                const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-                wait_vm<0>();
-                if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
-            }
-        };
 
-        // One K-tile: 4 k-steps of {6 ds_read_b128, 8 MFMA}.  The (4 + NT) LDS-DMA loads of the NEXT K-tile are
-        // issued two per k-step BETWEEN the fragment reads and the MFMAs, so their issue cost hides behind the
-        // matrix pipe instead of delaying the first MFMA after the barrier (cdna guide: "the per-phase interleave
-        // is the lever").
-        auto multiply = [&](int nstage, int nk0, bool do_load) {
+        // ---- accumulators start at the bias (fp32, added before the single bf16 rounding): scalar loads.  N % 64 == 0
+        //      (dispatch condition), so a wave's 64 columns are all inside or all outside the matrix ---------------------
+        f32x16 acc[MI][2];
+        {
+            const int cb = g.bias ? min(n0 + wn * 64, g.N - 64) : 0;       // wave-uniform first column
+            const __attribute__((address_space(4))) float* bp =
+                (const __attribute__((address_space(4))) float*)(unsigned long long)(g.bias ? g.bias + cb : g.zero_bias);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bp[j * 32 + q4 * 8 + e], up = bp[j * 32 + q4 * 8 + 4 + e];
+                        const float b = hi ? up : lo;
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) acc[i][j][q4 * 4 + e] = b;
+                    }
+        }
+
+        // One K-tile: 4 k-steps of {6 ds_read_b128, 8 MFMA}; with LOAD the 8 LDS-DMA loads of K-tile `k_next` (this tile's
+        // next one, or the next tile's first) go out two per k-step between the fragment reads and the MFMAs.
+        auto multiply = [&](auto load_tag, bool do_load, int k_next) {
+            constexpr bool LOAD = decltype(load_tag)::value;
             const char* Ab = smem + (cnt & 1) * STAGE;
             const char* Bb = Ab + BOFF;
-            char* sb = smem + nstage * STAGE + wave * 1024;
+            const unsigned sb = lds0 + ((cnt + 1) & 1) * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8 wf[2], af[MI];
@@ -204,13 +174,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                     const int r = wm * WR + t * 32 + frow;
                     af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
                 }
-                if (do_load) {                                // two of the next K-tile's LDS-DMA loads per k-step (measured: 4+4 in
-                                                              // the first two k-steps trades vmcnt wait for a longer barrier wait, -8 %)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[ks] + nk0),
-                                                     (__attribute__((address_space(3))) void*)(sb + ks * 8192), 16, 0, 0);
-                    if (ks < NT)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[ks < NT ? ks : 0] + nk0),
-                                                         (__attribute__((address_space(3))) void*)(sb + BOFF + ks * 8192), 16, 0, 0);
+                if (LOAD && do_load) {
+                    dma16(a_src[ks] + k_next, sb + ks * 8192);
+                    dma16(b_src[ks] + k_next, sb + BOFF + ks * 8192);
                 }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -222,94 +188,100 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             }
             ++cnt;
         };
+        using yes = std::true_type; using no = std::false_type;
 
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            top_wait(kt == 0);                                     // this wave's pieces of the current K-tile have landed
-            { const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-              s_barrier_lgkm();                                    // everyone's have; everyone is done with the other stage
-              if (g.tim) t_bar += __builtin_amdgcn_s_memtime() - w0; }
-            multiply((cnt + 1) & 1, (kt + 1) * TK, true);
+        // In flight at this point, oldest first: K-tile 0, K-tile 1, the previous epilogue's stores (nk >= 3: dispatch condition).
+        {
+            const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
+            if (pend == NSTORE) wait_vm<NSTORE + NL>(); else wait_vm<NL>();       // K-tile 0 has landed
+            if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
         }
-        // ---- last K-tile of this tile: the NEXT tile's first K-tile, the bias and the first residual rows are
-        //      requested now, so their latency hides behind these 32 MFMAs ---------------------------------------
-        top_wait(nk == 1);
         s_barrier_lgkm();
-        {   // every address is computed (and any spilled value reloaded) BEFORE the first load is issued, so that
-            // no compiler-inserted `s_waitcnt vmcnt(0)` lands behind freshly issued operand loads
-            const float* bp = g.bias ? g.bias + min(nn0 + wn * 64 + lane, g.N - 1) : nullptr;
-            if (has_next) set_src(nm0, nn0);
-            asm volatile("" : "+v"(bp) :: "memory");
-            if (has_next && g.bias) lds_dma4(bp, scratch_lds);
+        multiply(no{}, false, 0);                                                 // K-tile 1 was requested at the previous tile boundary
+        {
+            const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
+            if (pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>();             // K-tile 1 has landed; the stores may still fly
+            if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
         }
+        for (int kt = 1; kt + 1 < nk; ++kt) {
+            s_barrier_lgkm();                                                      // everyone's pieces have landed; everyone is done with the other stage
+            multiply(yes{}, true, (kt + 1) * TK);
+            wait_vm<0>();                                                          // this wave's pieces of K-tile kt + 1
+        }
+        // ---- tile boundary.  Order of the vector-memory queue from here (it retires in order):
+        //        residual rows of pass 0 | next tile's K-tile 0 (during the last multiply) | next tile's K-tile 1 |
+        //        residual rows of pass 1 | stores of pass 0 | residual 2 | stores 1 | residual 3 | stores 2 | stores 3
+        //      so the next tile waits vmcnt(NSTORE + 8) for its first K-tile and vmcnt(NSTORE) for its second, and no wait
+        //      in here asks for a store to have completed.
+        const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N) && !(g.dbg & 1);
+        const bool use_res = g.res && !(g.dbg & 2);
         const int slot = lane & 7;
         const int col = n0 + wn * 64 + slot * 8;
         const bool col_ok = col < g.N;
-        constexpr int NLD = RP / 8;
-        bf16x8 rv[HALVES][NLD];
-        auto load_residual = [&](int h) {
-            if (g.res && !(g.dbg & 2)) {
+        char* stg = smem + 2 * STAGE + wave * 4096;
+        bf16x8 rv[2][4];
+        auto load_residual = [&](auto int_tag, int h) {
 #pragma unroll
-                for (int it = 0; it < NLD; ++it) {
-                    const int grow = m0 + wm * WR + h * RP + it * 8 + (lane >> 3);
-                    if (grow < g.M && col_ok) rv[h][it] = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
-                }
+            for (int it = 0; it < 4; ++it) {
+                const int grow = m0 + wm * WR + h * 32 + it * 8 + (lane >> 3);
+                if (decltype(int_tag)::value || (grow < g.M && col_ok))
+                    rv[h & 1][it] = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
             }
         };
-        multiply((cnt + 1) & 1, 0, has_next);
+        s_barrier_lgkm();
+        if (has_next) set_src(nm0, nn0);                                           // addresses first, loads after: no reload lands behind a DMA
+        if (use_res) { if (interior) load_residual(yes{}, 0); else load_residual(no{}, 0); }
+        multiply(yes{}, has_next, 0);                                              // last K-tile; the next tile's first one goes out
         const unsigned long long ts1 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-        load_residual(0);
-        const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N) && !(g.dbg & 1);
-
-        // ---- epilogue: stage through the stage just consumed ((cnt-1)&1); the other one is receiving
-        //      the next tile's first K-tile --------------------------------------------------------
-        char* stg = smem + ((cnt - 1) & 1) * STAGE + wave * (RP * 128);
+        s_barrier_lgkm();                                                          // every wave is done with the stage just multiplied: it
+                                                                                   // receives the next tile's SECOND K-tile inside pass 0
+        // One 32-row MFMA tile per pass through this wave's private 4 KiB of staging.
+        auto epilogue = [&](auto res_tag, auto int_tag) {
+            constexpr bool RES = decltype(res_tag)::value, INT = decltype(int_tag)::value;
 #pragma unroll
-        for (int h = 0; h < HALVES; ++h) {
-            if (h == 0) s_barrier_lgkm();   // every wave's MFMA operand reads of this stage are done (a wave only ever
-                                            // touches its OWN staging rows afterwards, and LDS ops of one wave execute in order)
+            for (int h = 0; h < MI; ++h) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                    for (int ii = 0; ii < MI / HALVES; ++ii) {
-                        const int i = h * (MI / HALVES) + ii;
+                    for (int q4 = 0; q4 < 4; ++q4) {
                         bf16x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float x = acc[i][j][q4 * 4 + e];
+                            float x = acc[h][j][q4 * 4 + e];
                             if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
                             else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
                             v[e] = (bf16)x;
                         }
-                        const int row = ii * 32 + frow;
-                        *reinterpret_cast<bf16x4*>(stg + row * 128 + (((j * 4 + q4) ^ (row & 7)) << 4) + 8 * hi) = v;
+                        *reinterpret_cast<bf16x4*>(stg + frow * 128 + (((j * 4 + q4) ^ (frow & 7)) << 4) + 8 * hi) = v;
                     }
-            if (h + 1 < HALVES) load_residual(h + 1);            // requested before this pass's stores (vmcnt retires in order)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave re-reads only its own staging rows
-            constexpr int CH = NLD >= 4 ? NLD / 2 : NLD;           // two chunks keep the register footprint low
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // a wave re-reads only its own staging rows
+                bf16x8 ov[4];
 #pragma unroll
-            for (int c0 = 0; c0 < NLD; c0 += CH) {
-                bf16x8 ov[CH];
-#pragma unroll
-                for (int it = 0; it < CH; ++it) {
-                    const int row = (c0 + it) * 8 + (lane >> 3);
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3);
                     ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
                 }
+                if (RES) {
 #pragma unroll
-                for (int it = 0; it < CH; ++it) {
-                    const int grow = m0 + wm * WR + h * RP + (c0 + it) * 8 + (lane >> 3);
-                    if (grow < g.M && col_ok && !(g.dbg & 1)) {
-                        bf16x8 v = ov[it];
-                        if (g.res && !(g.dbg & 2)) {
+                    for (int it = 0; it < 4; ++it)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[h][c0 + it][e]);
-                        }
-                        *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = v;
-                    }
+                        for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[h & 1][it][e]);
+                }
+                if (h == 0) {
+                    asm volatile("" ::: "memory");
+                    if (has_next) issue_ktile((cnt + 1) & 1, TK);
+                }
+                if (RES && h + 1 < MI) load_residual(int_tag, h + 1);     // requested before this pass's stores (vmcnt retires in order)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int grow = m0 + wm * WR + h * 32 + it * 8 + (lane >> 3);
+                    if (INT || (grow < g.M && col_ok && !(g.dbg & 1)))
+                        *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = ov[it];
                 }
             }
-        }
+        };
+        if (use_res) { if (interior) epilogue(yes{}, yes{}); else epilogue(yes{}, no{}); }
+        else { if (interior) epilogue(no{}, yes{}); else epilogue(no{}, no{}); }
         if (g.tim) { const unsigned long long ts2 = __builtin_amdgcn_s_memtime(); t_main += ts1 - ts0; t_epi += ts2 - ts1; }
         if (!has_next) break;
         pend = interior ? NSTORE : -1;
@@ -452,21 +424,20 @@ int launch_tail(hipStream_t s, const PArgs& g, int act) {
     return SETOK_OK;
 }
 
-template <int NT>
-int launch_nt(hipStream_t s, const PArgs& g, int act, int n_cu) {
+int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
     static bool attr_set = false;
     if (!attr_set) {
-        bool ok = hipFuncSetAttribute((const void*)gemm_persist_kernel<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        bool ok = hipFuncSetAttribute((const void*)gemm_persist_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
         if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
-    if (act == SETOK_ACT_NONE) gemm_persist_kernel<NT, 0><<<grid, 512, LDS_BYTES, s>>>(g);
-    else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<NT, 1><<<grid, 512, LDS_BYTES, s>>>(g);
-    else gemm_persist_kernel<NT, 2><<<grid, 512, LDS_BYTES, s>>>(g);
+    if (act == SETOK_ACT_NONE) gemm_persist_kernel<0><<<grid, 512, MAIN_LDS, s>>>(g);
+    else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1><<<grid, 512, MAIN_LDS, s>>>(g);
+    else gemm_persist_kernel<2><<<grid, 512, MAIN_LDS, s>>>(g);
     SETOK_CHECK_LAUNCH("setok_linear(persistent)");
     return SETOK_OK;
 }
@@ -496,12 +467,16 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int tm_main = tilesM - p;
     static const int dbg = [] { const char* e = getenv("SETOK_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     if (dbg & 4) p = 0;
-    static const int stg = [] { const char* e = getenv("SETOK_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
-    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, stg, timing ? tim : nullptr};
-    int rc = launch_nt<4>(s, g, act, ncu);
+    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr};
+    if (!bias) {
+        static const float* zb = [] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(kZeroBias)) == hipSuccess ? (const float*)q : nullptr; }();
+        if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
+        g.zero_bias = zb;
+    }
+    int rc = launch_main(s, g, act, ncu);
     if (timing && tim) {
         unsigned long long h[256 * 4];
         if (hipMemcpy(h, tim, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -515,6 +490,6 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (rc != SETOK_OK || p == 0) return rc;
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
-            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TM), cdiv(N, 64), dbg, 0, nullptr};
+            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TM), cdiv(N, 64), dbg, nullptr, nullptr};
     return launch_tail(s, t, act);
 }

@@ -172,9 +172,16 @@ def cluster_dpc_knn(x: Tensor, B: int, N: int, k: int, threshold: float, min_clu
     if token_mask is not None:
         token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
         assert token_mask.numel() == B * N
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("setok_cluster_dpc_knn", _stream(), _code(x.dtype), _p(x), B, N, Cc, int(k), float(threshold),
               int(min_cluster_num), _p(noise), _p(token_mask), _p(idx), _p(score), _p(index_down), _p(counts),
               _p(dist_ws), _p(vec_ws))
+    if _PROFILE is not None:
+        e1.record()
+        # algorithmic bytes: read x once, write idx_cluster (int64), score (fp32), index_down (int64, <= N)
+        _PROFILE.append(("cluster_dpc_knn", float(B) * (N * Cc * x.element_size() + N * 8 + N * 4 + N * 8), e0, e1))
     return idx, score, index_down, counts
 
 

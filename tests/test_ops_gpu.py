@@ -60,7 +60,8 @@ def test_linear_bf16(M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K,act,res", [(4096, 4096, 1024, 1, True), (4100, 2056, 128, 0, False), (2560, 3072, 256, 2, True),
                                            (6000, 1024, 4096, 0, True), (8448, 2048, 512, 1, True), (65792, 1024, 128, 0, True),
-                                           (16640, 4096, 64, 2, False)])
+                                           (16640, 4096, 64, 2, False), (4100, 2112, 192, 0, True), (6000, 1024, 256, 1, False),
+                                           (25700, 1344, 320, 2, True), (66000, 768, 768, 0, True)])
 def test_linear_bf16_large_tiles(M, N, K, act, res):
     """Shapes with >= 96 output tiles take the 256x256 direct-to-LDS kernel (ragged M and N edges included)."""
     a, w = _rand(M, K, seed=1).bfloat16(), (_rand(N, K, seed=2, scale=K ** -0.5)).bfloat16()
@@ -75,6 +76,19 @@ def test_linear_bf16_large_tiles(M, N, K, act, res):
     # element-wise: at most one bf16 ulp (2^-8 relative) + accumulation-order noise
     err = (got.double().cpu() - ref).abs()
     assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all())
+
+
+def test_linear_bf16_large_no_bias_and_alias():
+    """Persistent kernel without a bias (scalar-loaded zero row) and with C aliasing the residual (in-place residual stream)."""
+    M, N, K = 8192, 3072, 1024
+    a, w = _rand(M, K, seed=1).bfloat16(), (_rand(N, K, seed=2, scale=K ** -0.5)).bfloat16()
+    ref = F.linear(a.double(), w.double())
+    got = ops.linear(a.to(DEV), w.to(DEV))
+    assert _rel_err(got, ref) < 6e-3
+    r = _rand(M, N, seed=4).bfloat16()
+    buf = r.to(DEV).clone()
+    ops.linear(a.to(DEV), w.to(DEV), None, residual=buf, out=buf)
+    assert _rel_err(buf, ref.bfloat16().double() + r.double()) < 6e-3
 
 
 def test_linear_transpose_detecting():
