@@ -143,6 +143,38 @@ int setok_gather_rows(void* stream, int dtype, const void* x, const int32_t* per
 int setok_segment_mean(void* stream, int dtype, const void* h, const int32_t* seg_offsets,
                        const int32_t* n_segs_dev, int max_segs, void* out, int C);
 
+/* ---- after the path: prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355) ------------------------------------
+ * The reference walks the batch in Python: strips padding by the mask (:258-259), cuts every sequence at its
+ * IMAGE_TOKEN_INDEX placeholders, embeds the text pieces, interleaves them with the images' (L_i, D) token matrices
+ * (:273-303), truncates (:311-314) and pads to the batch maximum (:317-339).  Here it is three asynchronous steps on device
+ * buffers; the host reads `seq_len` once in between to size the outputs (max over the batch, :317).
+ *
+ * img_offsets: int32[n_images + 1], row offsets of the packed image tokens (image i owns rows [off[i], off[i+1])).
+ * Images are consumed in batch order, one per placeholder; a sequence WITHOUT a placeholder still consumes one (:264-271). */
+
+/* Step 1.  seq_len[b] = tokens kept by the mask - placeholders + rows of the sequence's images, truncated to max_length
+ * (<= 0: no limit); img_start[b] = index of its first image; status[0] = 1 if the batch needs more than n_images images
+ * (the reference raises IndexError at image_features[cur_image_idx]), status[1] = images needed.  attention_mask: uint8
+ * (B,T), NULL = all kept (:250-251).  count_ws: int32[2*B] scratch. */
+int setok_splice_lengths(void* stream, const int64_t* input_ids, const uint8_t* attention_mask, int B, int T,
+                         int64_t image_token_index, const int32_t* img_offsets, int n_images, int max_length,
+                         int32_t* seq_len, int32_t* img_start, int32_t* status, int32_t* count_ws);
+
+/* Step 2.  For every output position (b, p), p < max_len: src (int32) = embedding-table row (token id) | -(image-token row + 1)
+ * | INT32_MIN for a zero padding row; new_labels (NULL iff labels is NULL, :341-342): the token's label, ignore_index on
+ * image rows (:293) and padding (:319), target_token_index mapped to ignore_index (:344); new_mask (uint8, optional);
+ * new_position_ids (int64, optional; 0..len-1 inside the kept range, 0 in the padding, :321,337).  left_pad selects
+ * tokenizer_padding_side == "left" (:324-330). */
+int setok_splice_plan(void* stream, const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels, int B, int T,
+                      int64_t image_token_index, int64_t ignore_index, int64_t target_token_index,
+                      const int32_t* img_offsets, const int32_t* seq_len, const int32_t* img_start, int max_len, int left_pad,
+                      int32_t* src, int64_t* new_labels, uint8_t* new_mask, int64_t* new_position_ids);
+
+/* Step 3.  out[r, :] = embed_table[src[r]] | image_tokens[-(src[r] + 1)] | 0, r < rows = B * max_len: embed_tokens (:266,284)
+ * fused with the concatenations and the zero padding (:296-303, 324-333).  D * sizeof(dtype) must be a multiple of 16. */
+int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* embed_table, int vocab, const void* image_tokens,
+                      void* out, int64_t rows, int D);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,73 @@ def rac_qformer(emb, enc, sd, query_embeds: torch.Tensor, encoder_hidden_states:
     out = enc(x, attention_mask=ext, head_mask=[None] * len(enc.layer), encoder_hidden_states=encoder_hidden_states,
               encoder_attention_mask=enc_ext, return_dict=True, query_length=Q)   # :984-996
     return out.last_hidden_state
+
+
+# ----------------------------------------------------------------------------------------------
+# §8(f) row 1 — the reference's own prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355), unmodified, on a host
+# object that supplies what the method reads: get_vision_tower() (non-None), encode_images() (returns the per-image token
+# matrices handed in — the encoder itself is rows a1-a8), get_model().embed_tokens, config, device.
+# ----------------------------------------------------------------------------------------------
+def load_reference_arch():
+    name = "rac_src_model.setokim_arch"
+    if name in sys.modules:
+        return sys.modules[name]
+    model_dir = os.path.join(REF_ROOT, "src", "model")
+    for pkg, path in (("src", os.path.join(REF_ROOT, "src")), ("rac_src_model", model_dir)):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [path]
+            m.__spec__ = importlib.machinery.ModuleSpec(pkg, loader=None, is_package=True)
+            sys.modules[pkg] = m
+    spec = importlib.util.spec_from_file_location("src.constants", os.path.join(REF_ROOT, "src", "constants.py"))
+    const = importlib.util.module_from_spec(spec); sys.modules["src.constants"] = const; spec.loader.exec_module(const)
+    # the builders / loss imported at module top (setokim_arch.py:21-24) are not used by the method under test
+    for sub, names in (("multimodal_encoder.builder", ["build_vision_tower"]), ("multimodal_projector.builder", ["build_vision_projector"]),
+                       ("multimodal_generator.builder", ["build_vision_generator"]), ("loss", ["DiffLoss"])):
+        parts = sub.split(".")
+        for i in range(1, len(parts) + 1):
+            full = "rac_src_model." + ".".join(parts[:i])
+            if full not in sys.modules:
+                m = types.ModuleType(full); m.__path__ = []
+                m.__spec__ = importlib.machinery.ModuleSpec(full, loader=None, is_package=True)
+                sys.modules[full] = m
+        for n in names:
+            setattr(sys.modules["rac_src_model." + sub], n, None)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(model_dir, "setokim_arch.py"))
+    mod = importlib.util.module_from_spec(spec); sys.modules[name] = mod; spec.loader.exec_module(mod)
+    return mod
+
+
+@torch.no_grad()
+def rac_prepare_inputs(input_ids, position_ids, attention_mask, labels, image_features, embed_weight,
+                       max_length=None, padding_side="right"):
+    arch = load_reference_arch()
+    emb = torch.nn.Embedding.from_pretrained(embed_weight, freeze=True)
+
+    class _Model:
+        embed_tokens = emb
+
+    class _Cfg:
+        pass
+    cfg = _Cfg()
+    if max_length is not None:
+        cfg.tokenizer_model_max_length = max_length
+    cfg.tokenizer_padding_side = padding_side
+
+    class Host(arch.SetokimMetaForCausalLM):
+        config = cfg
+        device = embed_weight.device
+
+        def get_model(self):
+            return _Model()
+
+        def get_vision_tower(self):
+            return object()
+
+        def encode_images(self, images):
+            return image_features
+
+    images = torch.zeros(len(image_features), 3, 2, 2)          # only `images is None` / `.ndim` are looked at (:219-227)
+    out = Host().prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, None, labels, images)
+    _, pos, am, _, embeds, new_labels = out
+    return pos, am, embeds, new_labels

@@ -573,6 +573,91 @@ def init_detok_weights(dc: DetokConfig, seed: int = 3, dtype=torch.float32) -> D
 
 
 # ----------------------------------------------------------------------------------------------
+# §8(f) row 1 — prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355): the ragged splice
+# ----------------------------------------------------------------------------------------------
+IGNORE_INDEX, IMAGE_TOKEN_INDEX, TARGET_TOKEN_INDEX = -100, -200, -300          # src/constants.py:7-8,15
+
+
+def splice_multimodal(input_ids: Tensor, position_ids: Optional[Tensor], attention_mask: Optional[Tensor],
+                      labels: Optional[Tensor], image_features: Sequence[Tensor], embed_weight: Tensor,
+                      max_length: Optional[int] = None, padding_side: str = "right"):
+    """The data path of `prepare_inputs_labels_for_multimodal` after `encode_images` (setokim_arch.py:241-353), given the
+    per-image token matrices `image_features[i]` (L_i, D) and the LLM's embedding table.  Returns
+    (position_ids, attention_mask, inputs_embeds, labels) with the reference's None conventions (:341-353).
+
+    Per sequence (:262-308): padding removed by the mask (:258-259); every IMAGE_TOKEN_INDEX placeholder is replaced by the
+    next image's tokens (labels IGNORE_INDEX, :292-293), text tokens by their embedding rows; a sequence WITHOUT a placeholder
+    still consumes one image index (:264-271).  Then truncation (:311-314), padding to the batch maximum on the configured
+    side with zero rows / IGNORE_INDEX / False / 0 (:317-337), TARGET_TOKEN_INDEX labels -> IGNORE_INDEX (:344)."""
+    B, T = input_ids.shape
+    am = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
+    lab = torch.full_like(input_ids, IGNORE_INDEX) if labels is None else labels
+    D = embed_weight.shape[1]
+    rows_all, labs_all = [], []
+    img = 0
+    for b in range(B):
+        ids, lb = input_ids[b][am[b]], lab[b][am[b]]
+        rows, labs = [], []
+        n_img = int((ids == IMAGE_TOKEN_INDEX).sum())
+        if n_img == 0:
+            _ = image_features[img]                                         # :265 (indexing happens, so it can raise)
+            img += 1
+        for t in range(ids.shape[0]):
+            if int(ids[t]) == IMAGE_TOKEN_INDEX:
+                f = image_features[img]; img += 1
+                rows.append(f)
+                labs.append(torch.full((f.shape[0],), IGNORE_INDEX, dtype=lb.dtype))
+            else:
+                rows.append(embed_weight[int(ids[t])][None])
+                labs.append(lb[t:t + 1])
+        r = torch.cat(rows, 0) if rows else embed_weight.new_zeros((0, D))
+        l = torch.cat(labs, 0) if labs else lb.new_zeros((0,))
+        if max_length is not None:
+            r, l = r[:max_length], l[:max_length]
+        rows_all.append(r); labs_all.append(l)
+    max_len = max(r.shape[0] for r in rows_all)
+    emb = embed_weight.new_zeros((B, max_len, D))
+    new_labels = torch.full((B, max_len), IGNORE_INDEX, dtype=lab.dtype)
+    new_am = torch.zeros((B, max_len), dtype=torch.bool)
+    new_pos = torch.zeros((B, max_len), dtype=torch.long if position_ids is None else position_ids.dtype)
+    for b, (r, l) in enumerate(zip(rows_all, labs_all)):
+        n = r.shape[0]
+        if n == 0:
+            continue
+        sl = slice(max_len - n, max_len) if padding_side == "left" else slice(0, n)
+        emb[b, sl] = r; new_labels[b, sl] = l; new_am[b, sl] = True
+        new_pos[b, sl] = torch.arange(n, dtype=new_pos.dtype)
+    new_labels[new_labels == TARGET_TOKEN_INDEX] = IGNORE_INDEX
+    return (None if position_ids is None else new_pos,
+            None if attention_mask is None else new_am.to(attention_mask.dtype),
+            emb,
+            None if labels is None else new_labels)
+
+
+def splice_inputs(seed, B, T, V, D, max_imgs=3, pad=True):
+    """Seeded inputs of prepare_inputs_labels_for_multimodal: ids with placeholders (-200), a prefix mask, labels with a few
+    TARGET (-300) entries, ragged image tokens.  Regenerates bit-exactly from the seed (torch CPU generator)."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, V, (B, T), generator=g)
+    am = torch.ones(B, T, dtype=torch.long)
+    n_need = 0
+    for b in range(B):
+        n_valid = int(torch.randint(1, T + 1, (1,), generator=g)) if pad else T
+        am[b, n_valid:] = 0
+        n_img = int(torch.randint(0, max_imgs + 1, (1,), generator=g))
+        n_img = min(n_img, n_valid)
+        where = torch.randperm(n_valid, generator=g)[:n_img]
+        ids[b, where] = IMAGE_TOKEN_INDEX
+        n_need += max(n_img, 1)
+    labels = torch.where(am.bool(), torch.randint(0, V, (B, T), generator=g), torch.full((B, T), IGNORE_INDEX))
+    tgt = torch.rand(B, T, generator=g) < 0.05
+    labels[tgt & am.bool()] = TARGET_TOKEN_INDEX
+    feats = [torch.randn(int(torch.randint(1, 9, (1,), generator=g)), D, generator=g) for _ in range(n_need)]
+    W = torch.randn(V, D, generator=g)
+    return ids, am, labels, feats, W
+
+
+# ----------------------------------------------------------------------------------------------
 # seeded synthetic weights (no pretrained weights / network exist: SURVEY.md §8d)
 # ----------------------------------------------------------------------------------------------
 def init_head_weights(hc: HeadConfig, seed: int = 1, dtype=torch.float32) -> Dict[str, Tensor]:

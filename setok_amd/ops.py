@@ -215,3 +215,49 @@ def activation(x: Tensor, act: int, out: Optional[Tensor] = None) -> Tensor:
         out = torch.empty_like(x)
     _lib.call("setok_activation", _stream(), _code(x.dtype), _p(x), _p(out), x.numel(), act)
     return out
+
+
+# ---- prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355) --------------------------------------------------------
+def splice_lengths(input_ids: Tensor, attention_mask: Optional[Tensor], img_offsets: Tensor, n_images: int, image_token_index: int,
+                   max_length: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Returns (seq_len int32 (B,), img_start int32 (B,), status int32 (2,)) on the device; no host synchronisation."""
+    B, T = input_ids.shape
+    dev = input_ids.device
+    assert input_ids.dtype == torch.int64 and img_offsets.dtype == torch.int32 and img_offsets.numel() >= n_images + 1
+    if attention_mask is not None:
+        assert attention_mask.dtype == torch.uint8 and attention_mask.shape == (B, T)
+    seq_len = torch.empty((B,), dtype=torch.int32, device=dev)
+    img_start = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((2,), dtype=torch.int32, device=dev)
+    ws = torch.empty((2 * B,), dtype=torch.int32, device=dev)
+    _lib.call("setok_splice_lengths", _stream(), _p(input_ids), _p(attention_mask), B, T, image_token_index, _p(img_offsets), n_images,
+              int(max_length), _p(seq_len), _p(img_start), _p(status), _p(ws))
+    return seq_len, img_start, status
+
+
+def splice_plan(input_ids: Tensor, attention_mask: Optional[Tensor], labels: Optional[Tensor], img_offsets: Tensor, seq_len: Tensor,
+                img_start: Tensor, max_len: int, left_pad: bool, image_token_index: int, ignore_index: int, target_token_index: int,
+                want_mask: bool, want_pos: bool):
+    B, T = input_ids.shape
+    dev = input_ids.device
+    src = torch.empty((B, max_len), dtype=torch.int32, device=dev)
+    new_labels = torch.empty((B, max_len), dtype=torch.int64, device=dev) if labels is not None else None
+    new_mask = torch.empty((B, max_len), dtype=torch.uint8, device=dev) if want_mask else None
+    new_pos = torch.empty((B, max_len), dtype=torch.int64, device=dev) if want_pos else None
+    if labels is not None:
+        assert labels.dtype == torch.int64 and labels.shape == (B, T)
+    _lib.call("setok_splice_plan", _stream(), _p(input_ids), _p(attention_mask), _p(labels), B, T, image_token_index, ignore_index,
+              target_token_index, _p(img_offsets), _p(seq_len), _p(img_start), max_len, 1 if left_pad else 0, _p(src), _p(new_labels),
+              _p(new_mask), _p(new_pos))
+    return src, new_labels, new_mask, new_pos
+
+
+def splice_rows(src: Tensor, embed_table: Tensor, image_tokens: Optional[Tensor]) -> Tensor:
+    B, max_len = src.shape
+    V, D = embed_table.shape
+    out = torch.empty((B, max_len, D), dtype=embed_table.dtype, device=embed_table.device)
+    if image_tokens is not None:
+        assert image_tokens.dtype == embed_table.dtype and image_tokens.shape[-1] == D
+    _lib.call("setok_splice_rows", _stream(), _code(embed_table.dtype), _p(src), _p(embed_table), V, _p(image_tokens), _p(out),
+              B * max_len, D)
+    return out

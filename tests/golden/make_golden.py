@@ -225,10 +225,43 @@ def gen_detok():
     save("detok", **arrs)
 
 
+# ----------------------------------------------------------------------------------------------
+SPLICE_CASES = {
+    # name: (seed, B, T, V, D, kwargs)
+    "right": (1, 5, 12, 40, 16, dict()),
+    "left": (2, 5, 12, 40, 16, dict(padding_side="left")),
+    "trunc": (3, 6, 10, 40, 16, dict(max_length=9)),
+    "trunc_left": (4, 6, 10, 40, 16, dict(max_length=7, padding_side="left")),
+    "nopad_long": (5, 3, 300, 64, 8, dict()),
+}
+
+
+def gen_splice():
+    """§8(f) row 1: the reference's own prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355), run unmodified
+    (oracle/rac_harness.py::rac_prepare_inputs).  Stored: seeds/specs and the REFERENCE's outputs, with and without the
+    optional inputs (position_ids / attention_mask / labels None)."""
+    arrs = {}
+    for name, (seed, B, T, V, D, kw) in SPLICE_CASES.items():
+        ids, am, labels, feats, W = O.splice_inputs(seed, B, T, V, D, pad=not name.startswith("nopad"))
+        pos = torch.arange(T).expand(B, T).clone()
+        arrs[name + ":spec"] = np.array([seed, B, T, V, D, kw.get("max_length", -1), 1 if kw.get("padding_side") == "left" else 0])
+        for variant, (p_, a_, l_) in {"full": (pos, am, labels), "none": (None, None, None)}.items():
+            rp, ra, re, rl = R.rac_prepare_inputs(ids, p_, a_, l_, feats, W, **kw)
+            arrs[f"{name}:{variant}:embeds"] = npy(re)
+            if rp is not None:
+                arrs[f"{name}:{variant}:pos"] = npy(rp); arrs[f"{name}:{variant}:mask"] = npy(ra); arrs[f"{name}:{variant}:labels"] = npy(rl)
+            else:
+                assert ra is None and rl is None
+        print(name, "reference output", tuple(re.shape))
+    save("splice", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok"]
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice"]
     if "detok" in which:
         gen_detok()
+    if "splice" in which:
+        gen_splice()
     if "head_small" in which:
         gen_head_small()
     if "cluster_full" in which:

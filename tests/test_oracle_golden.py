@@ -213,3 +213,35 @@ def test_detokenizer_pos_table_width():
     sd = O.init_detok_weights(dc)
     with pytest.raises(ValueError):                      # the reference's `x + pos_emb` cannot broadcast 16 -> 32 channels
         O.detokenizer_forward(sd, dc, torch.randn(1, 3, 8), None)
+
+
+# ---- §8(f) row 1: prepare_inputs_labels_for_multimodal ---------------------------------------------------------------
+SPLICE_NAMES = ["right", "left", "trunc", "trunc_left", "nopad_long"]
+
+
+def _splice_case(golden_dir, name):
+    z = _load(golden_dir, "splice")
+    seed, B, T, V, D, maxlen, left = [int(v) for v in z[name + ":spec"]]
+    ids, am, labels, feats, W = O.splice_inputs(seed, B, T, V, D, pad=not name.startswith("nopad"))
+    kw = dict(max_length=None if maxlen < 0 else maxlen, padding_side="left" if left else "right")
+    return z, ids, am, labels, feats, W, kw
+
+
+@pytest.mark.parametrize("name", SPLICE_NAMES)
+def test_splice_matches_reference(golden_dir, name):
+    """oracle.splice_multimodal against the outputs of the reference's own prepare_inputs_labels_for_multimodal: bit-exact."""
+    z, ids, am, labels, feats, W, kw = _splice_case(golden_dir, name)
+    T = ids.shape[1]
+    pos = torch.arange(T).expand(ids.shape[0], T).clone()
+    p, a, e, l = O.splice_multimodal(ids, pos, am, labels, feats, W, **kw)
+    assert torch.equal(e, _t(z[f"{name}:full:embeds"])) and torch.equal(p, _t(z[f"{name}:full:pos"]))
+    assert torch.equal(a, _t(z[f"{name}:full:mask"])) and torch.equal(l, _t(z[f"{name}:full:labels"]))
+    assert a.dtype == am.dtype and not bool((l == O.TARGET_TOKEN_INDEX).any())
+    p, a, e, l = O.splice_multimodal(ids, None, None, None, feats, W, **kw)
+    assert p is None and a is None and l is None and torch.equal(e, _t(z[f"{name}:none:embeds"]))
+
+
+def test_splice_needs_enough_images():
+    ids, am, labels, feats, W = O.splice_inputs(7, 4, 10, 30, 8)
+    with pytest.raises(IndexError):
+        O.splice_multimodal(ids, None, am, labels, feats[:-1], W)

@@ -96,3 +96,18 @@ def test_qformer_restatement_vs_reference_live():
     torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
     ref_nomask = R.rac_qformer(emb, enc, sd, q, x, None)
     torch.testing.assert_close(O.qformer_forward(sd, dc, q, x, None), ref_nomask, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(padding_side="left"), dict(max_length=11), dict(max_length=5, padding_side="left")])
+def test_splice_restatement_vs_reference_live(kw):
+    """§8(f) row 1: oracle.splice_multimodal against the reference's prepare_inputs_labels_for_multimodal
+    (setokim_arch.py:213-355) executed unmodified; every output tensor bit-equal, None conventions included."""
+    ids, am, labels, feats, W = O.splice_inputs(21, 6, 14, 50, 12)
+    pos = torch.arange(14).expand(6, 14).clone()
+    for p_, a_, l_ in ((pos, am, labels), (None, None, None), (None, am.bool(), labels), (pos, am, None)):
+        ref = R.rac_prepare_inputs(ids, p_, a_, l_, feats, W, **kw)
+        got = O.splice_multimodal(ids, p_, a_, l_, feats, W, **kw)
+        for r, g in zip(ref, got):
+            assert (r is None) == (g is None)
+            if r is not None:
+                assert r.dtype == g.dtype and torch.equal(r, g)
