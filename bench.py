@@ -42,11 +42,30 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def build_model(device):
+WORKLOADS = {
+    # name: (image size, images per GPU, decoder?, description)
+    "cfg2": (224, 256, False, "cfg2: ViT-L/14 224^2 (23 of 24 layers, select_layer=-2), dyn-k DPC-kNN (k=64, threshold=0.125), SeTok head "
+                               "1024/2 heads/ff 4096 -> 4096, mm_in_projector mlp2x_gelu; encode-only"),
+    "cfg4-forward": (336, 128, False, "cfg4 shapes, FORWARD ONLY (the training step is not built): ViT-L/14 336^2 = 576 patches, dyn-k, batch 128 "
+                                       "per GPU, same head and projector as cfg2"),
+    "cfg3": (224, 256, True, "cfg3: cfg2 encode + reconstruction decoder (SetokDeTokenizer: token_feat_dim 4096 -> Q-Former 768/12 heads/6 layers, "
+                              "324 queries (image_size 256 / 14), cross-attention every 2nd layer -> 16 x ViT block 768/16 heads -> LayerNorm); "
+                              "no loss (the reference's GANLoss path is out of scope)"),
+}
+
+
+def build_decoder(device):
+    import setok_amd
+    det = setok_amd.SetokDeTokenizer(token_feat_dim=4096, hidden_dim=768, patch_size=14, image_size=256, decoder_embed_dim=768,
+                                     decoder_nheads=16, decoder_depth=16, feature_mapper_path_or_name="bert-base-uncased")
+    return det.to(device=device, dtype=torch.bfloat16).eval()
+
+
+def build_model(device, img=IMG):
     import setok_amd
     from setok_amd.synthetic import init_synthetic_
     vit = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
-               image_size=IMG, patch_size=PATCH)
+               image_size=img, patch_size=PATCH)
     tok = setok_amd.SetokTokenizer(vision_tower=vit, mm_vision_select_layer=-2, hidden_dim=1024, token_feat_dim=4096,
                                    min_cluster_num=64, threshold=THRESHOLD, nheads=2, dim_feedforward=4096)
     init_synthetic_(tok, tower_seed=0, head_seed=1)
@@ -136,8 +155,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 is the BASELINE.json metric; the others are additional measurements (no cpu_baseline leg)")
     args = ap.parse_args()
+    img, b_default, with_decoder, workload_desc = WORKLOADS[args.workload]
+    if args.batch is None:
+        args.batch = b_default
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,14 +179,19 @@ def main():
     import setok_amd
     from setok_amd import ops
     log(f"rank {rank}/{world}: building model")
-    tok, proj = build_model(dev)
+    tok, proj = build_model(dev, img)
+    det = build_decoder(dev) if with_decoder else None
     log("model on device")
     B = args.batch
     g = torch.Generator().manual_seed(3 + rank)
-    images = torch.randn(B, 3, IMG, IMG, generator=g).to(device=dev, dtype=torch.bfloat16)   # resident in HBM
+    images = torch.randn(B, 3, img, img, generator=g).to(device=dev, dtype=torch.bfloat16)   # resident in HBM
 
     def step():
-        return setok_amd.encode_images(tok, proj, images)
+        if det is None:
+            return setok_amd.encode_images(tok, proj, images)
+        tokens, _, _ = tok(images)                   # SeTok.forward (src/model/setok/model.py:87-88): tokenize, then detokenize
+        step.recon = det(tokens)
+        return tokens
 
     def barrier():
         if dist is not None:
@@ -198,16 +227,14 @@ def main():
         g_fl = sum(p["flops"] for p in gemm)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         res = {
-            "metric": "images/s SeTok encode (ViT-L/14, 224^2, dyn-k)",
+            "metric": "images/s SeTok encode (ViT-L/14, 224^2, dyn-k)" if args.workload == "cfg2" else f"images/s SeTok {args.workload}",
             "value": round(world * B * args.steps / dt, 2),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "cfg2: ViT-L/14 224^2 (23 of 24 layers, select_layer=-2), dyn-k DPC-kNN (k=64, "
-                                   "threshold=0.125), SeTok head 1024/2 heads/ff 4096 -> 4096, mm_in_projector mlp2x_gelu; "
-                                   "encode-only", "batch_per_gpu": B, "global_batch": world * B,
+            "config": {"workload": workload_desc, "batch_per_gpu": B, "global_batch": world * B,
                        "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
                        "sharding": f"dp{world} (images sharded, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<*> (bf16 MFMA GEMM of every large Linear)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
@@ -230,7 +257,7 @@ def main():
                 pk = PEAK_BF16_TFLOPS * telemetry["sclk_mhz_under_load"] / 2400.0
                 res["roofline"]["peak_at_measured_clock"] = round(pk, 1)
                 res["roofline"]["frac_at_measured_clock"] = round(achieved / pk, 4)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             res["cpu_baseline"] = cpu_baseline(tok, proj)
         else:
             res["cpu_baseline"] = None

@@ -15,8 +15,7 @@
 
 namespace {
 
-constexpr int DH = 64;
-constexpr int ROWB = DH * 2;            // 128 bytes per K / V row in LDS
+constexpr int ROWB = 128;              // bytes per K / V row in LDS: 64 dims; a 48-dim head leaves two 16-byte slots of each row unused
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
 
@@ -31,7 +30,9 @@ __device__ inline bf16x8 pack8(const float* p) {
 // query self-attention).  CROSS = true: the Tq query rows of image b (buffer qkv, row stride ldq) attend to the ragged key
 // / value segment [kv_offsets[b], kv_offsets[b+1]) of kptr / vptr (row stride ldkv) — the Q-Former's cross-attention to
 // the image's cluster tokens (module.py:283-286), the additive -10000 mask of the padded reference realised as a segment.
-template <int NW, bool CROSS>
+// DH = 64 or 48 (the decoder's 768 / 16 heads): 48 runs three QK^T k-steps instead of four and stores 48 of the 64 output
+// columns of the two PV tiles (the LDS slots past the head hold a copy of the head's first chunk: they only reach the unstored columns).
+template <int NW, bool CROSS, int DH>
 __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                            int T, int H, float scale_log2e, int64_t ldq,
                                                            const bf16* __restrict__ kptr, const bf16* __restrict__ vptr,
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
         for (int p0 = wave_u * 64; p0 < npieces; p0 += NW * 64) {    // this wave's 64 consecutive pieces
             const int p = p0 + lane, key = p >> 3, c = p & 7;
             const int64_t roff = (int64_t)min(key, T - 1) * ldk;
-            const bf16* ksrc = kbase + roff + ((c ^ (key & 7)) << 3);   // physical slot c of row `key` holds logical chunk c ^ (key & 7)
-            const bf16* vsrc = vbase + roff + (c << 3);
+            const int kc = c ^ (key & 7);                               // physical slot c of row `key` holds logical chunk c ^ (key & 7)
+            const bf16* ksrc = kbase + roff + ((kc < DH / 8 ? kc : 0) << 3);   // chunks past the head are never read back: fetch something valid
+            const bf16* vsrc = vbase + roff + ((c < DH / 8 ? c : 0) << 3);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(ksrc), "s"(lds0 + p0 * 16) : "memory");
@@ -91,9 +93,10 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     for (int qt = wave; qt < nq; qt += NW) {
         const int q = qt * 32 + qi;
         const bf16* qp = base + (int64_t)min(q, Tq - 1) * ld + hi * 8;
-        bf16x8 qf[4];
+        constexpr int NKS = DH / 16;
+        bf16x8 qf[NKS];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
 
         f32x16 o[2];
 #pragma unroll
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const int krow = kt * 32 + qi;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow * ROWB + (((ks * 2 + hi) ^ (krow & 7)) << 4));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
+                    if (d * 32 + 8 * r4 >= DH) continue;                          // DH = 48: the second tile's upper half does not exist
                     bf16x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[d][r4 * 4 + j] * inv);
@@ -171,17 +175,17 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     }
 }
 
-template <int NW>
+template <int NW, int DH>
 int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, float scale) {
     const int Tp = (T + 31) & ~31;
     const size_t smem = (size_t)Tp * ROWB * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
         attr_set = true;
     }
-    attn_vit_kernel<NW, false><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
+    attn_vit_kernel<NW, false, DH><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
                                                                       0, nullptr, 0, 0);
     SETOK_CHECK_LAUNCH("setok_attention(vit bf16)");
     return SETOK_OK;
@@ -194,11 +198,11 @@ int launch_cross(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const
     const size_t smem = (size_t)Tp * ROWB * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return setok_fail(SETOK_ELAUNCH, "cross attention: cannot raise dynamic LDS limit");
         attr_set = true;
     }
-    attn_vit_kernel<NW, true><<<dim3(H, n_segs), NW * 64, smem, s>>>(q, out, max_kv, H, scale * 1.44269504088896340736f, ldq, k, v, ldkv,
+    attn_vit_kernel<NW, true, 64><<<dim3(H, n_segs), NW * 64, smem, s>>>(q, out, max_kv, H, scale * 1.44269504088896340736f, ldq, k, v, ldkv,
                                                                      kv_offsets, q_len, ldo);
     SETOK_CHECK_LAUNCH("setok_cross_attention(bf16 mfma)");
     return SETOK_OK;
@@ -207,16 +211,21 @@ int launch_cross(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const
 }  // namespace
 
 int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, int Dh, float scale) {
-    if (Dh != DH || T < 1 || (size_t)((T + 31) & ~31) * ROWB * 2 > 160 * 1024) return SETOK_EUNSUPPORTED;
+    if ((Dh != 64 && Dh != 48) || T < 1 || (size_t)((T + 31) & ~31) * ROWB * 2 > 160 * 1024) return SETOK_EUNSUPPORTED;
     const int nq = (T + 31) >> 5;
+    if (Dh == 48) {                                                   // the reconstruction decoder's ViT blocks (768 / 16 heads)
+        if (nq >= 8) return launch<8, 48>(s, qkv, out, n_imgs, T, H, scale);
+        if (nq >= 4) return launch<4, 48>(s, qkv, out, n_imgs, T, H, scale);
+        return launch<1, 48>(s, qkv, out, n_imgs, T, H, scale);
+    }
     // T = 257 (ViT-L/14-224): 8 waves x 32 rows + the class-token row as a second pass of wave 0.  8-wave workgroups
     // fit two per CU (16 waves at 125 VGPRs), 9-wave ones only one: measured 202 vs 242 us per layer.  (Splitting the
     // class-token tile's keys across the 8 waves and merging partial softmaxes through LDS was tried: no gain — the
     // kernel is bound by aggregate VALU/LDS issue, not by the longest wave.)
-    if (nq >= 9) return launch<8>(s, qkv, out, n_imgs, T, H, scale);
-    if (nq >= 7) return launch<7>(s, qkv, out, n_imgs, T, H, scale);
-    if (nq >= 4) return launch<4>(s, qkv, out, n_imgs, T, H, scale);
-    return launch<1>(s, qkv, out, n_imgs, T, H, scale);
+    if (nq >= 9) return launch<8, 64>(s, qkv, out, n_imgs, T, H, scale);
+    if (nq >= 7) return launch<7, 64>(s, qkv, out, n_imgs, T, H, scale);
+    if (nq >= 4) return launch<4, 64>(s, qkv, out, n_imgs, T, H, scale);
+    return launch<1, 64>(s, qkv, out, n_imgs, T, H, scale);
 }
 
 // Q-Former cross-attention (module.py:283-286,303,342-364): head dim 64, ragged key segments of at most max_kv rows.

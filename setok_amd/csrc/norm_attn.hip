@@ -185,7 +185,7 @@ extern "C" int setok_attention(void* stream, int dtype, const void* qkv, const i
     SETOK_CHECK_ARG(seg_offsets == nullptr || n_segs > 0, "setok_attention: n_segs must be > 0 with seg_offsets");
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SETOK_BF16 && !seg_offsets && Dh == 64 && rows % seg_len == 0) {
+    if (dtype == SETOK_BF16 && !seg_offsets && (Dh == 64 || Dh == 48) && rows % seg_len == 0) {
         const int rc = setok_attention_vit_bf16(s, (const bf16*)qkv, (bf16*)out, rows / seg_len, seg_len, H, Dh, scale);
         if (rc != SETOK_EUNSUPPORTED) return rc;
     }

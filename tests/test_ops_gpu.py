@@ -124,7 +124,8 @@ def _attn_ref(qkv, H, Dh, scale, offsets):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("T,H,Dh,nimg", [(17, 4, 16, 3), (257, 16, 64, 2), (65, 2, 512, 2), (197, 12, 64, 1)])
+@pytest.mark.parametrize("T,H,Dh,nimg", [(17, 4, 16, 3), (257, 16, 64, 2), (65, 2, 512, 2), (197, 12, 64, 1), (324, 16, 48, 2), (33, 3, 48, 3),
+                                          (256, 12, 64, 2), (577, 16, 64, 1), (40, 2, 96, 2)])
 def test_attention_uniform(dt, tol, T, H, Dh, nimg):
     qkv = _rand(nimg * T, 3 * H * Dh, seed=8).to(dt)
     ref = _attn_ref(qkv, H, Dh, Dh ** -0.5, [i * T for i in range(nimg + 1)])
