@@ -291,116 +291,109 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Tail kernel: the < 1-round remainder of M (p*256 rows) as 256 x 64 tiles, ONE tile per workgroup.
-// These launches are latency-bound (few workgroups, 16-64 K-tiles each), so the 40 KiB stages are
-// triple-buffered: two K-tiles of operands are in flight while one is multiplied.
+// Tail kernel: the < 1-round remainder of M (p*256 rows; the ViT's 257 tokens per image leave one 256-row slab after every
+// exact number of rounds).  A handful of tiles cannot fill 256 CUs, so this launch is pure latency: with 256 x 64 tiles and three
+// stages it took 24 us (16 K-tiles at 1.5 us each) for 0.4 % of the GEMM's work — 7 % of its time.  Hence small tiles and a deep
+// pipeline: 64 x 64 tiles (4 waves, one 32 x 32 MFMA tile each), EIGHT 16 KiB stages, seven K-tiles of operands in flight, every
+// wait counted.  Same arithmetic per output element as the main kernel (bias as accumulator init, ascending k, one bf16 rounding,
+// round-then-add residual): a row's result does not depend on which kernel produced it.
 // --------------------------------------------------------------------------------------------
-constexpr int TSTAGE = 40 * 1024;                // A 32 KiB + W 8 KiB
-constexpr int TAIL_LDS = 3 * TSTAGE + 256;       // + bias row
+constexpr int TT = 64;                           // tail tile edge
+constexpr int TSTAGE = 2 * TT * TK * 2;          // A 8 KiB + W 8 KiB
+constexpr int TNS = 8;                           // stages
+constexpr int TAIL_LDS = TNS * TSTAGE + 256;     // + bias row
 
 template <int ACT>
-__global__ __launch_bounds__(512) void gemm_tail_kernel(PArgs g) {
+__global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 31, hi = lane >> 5;
     const int nk = g.K / TK;
-    const int m0 = (blockIdx.x / g.tilesN) * TM, n0 = (blockIdx.x % g.tilesN) * 64;
-    float* sbias = reinterpret_cast<float*>(smem + 3 * TSTAGE);
+    const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TT;
+    float* sbias = reinterpret_cast<float*>(smem + TNS * TSTAGE);
     if (tid < 64) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
 
-    const bf16* a_src[4]; const bf16* b_src;
+    const bf16* a_src[2]; const bf16* b_src[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
+    for (int i = 0; i < 2; ++i) {
+        const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
         a_src[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-        if (i == 0) b_src = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
+        b_src[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
     }
-    // LDS-DMA through inline asm: with two K-tiles (10 loads per lane) in flight hipcc's waitcnt pass runs out of
-    // tracked LDS-DMA slots (8) and falls back to `s_waitcnt vmcnt(0)` in front of every ds_read, which serialises the
-    // whole pipeline (measured: 2.4 us per K-tile instead of 0.6).  All waits in this loop are the explicit ones below.
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
     auto dma16 = [&](const bf16* ptr, unsigned lds_dst) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(ptr), "s"(lds_dst) : "memory");
     };
-    auto issue = [&](int stage, int k0, int i) {            // piece i of a K-tile: A chunk i (+ the W chunk with i == 0)
-        const unsigned sb = lds0 + stage * TSTAGE;
-        dma16(a_src[i] + k0, sb + i * 8192);
-        if (i == 0) dma16(b_src + k0, sb + BOFF);
+    auto issue = [&](int kt) {                              // 4 loads per lane per K-tile
+        const unsigned sb = lds0 + (kt % TNS) * TSTAGE;
+        const int k0 = kt * TK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(a_src[i] + k0, sb + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(b_src[i] + k0, sb + TT * TK * 2 + i * 4096);
     };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue(0, 0, i);
-    if (nk > 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue(1, TK, i);
-    }
-    f32x16 acc[2];
+    for (int kt = 0; kt < TNS - 1 && kt < nk; ++kt) issue(kt);
+
+    f32x16 acc;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vm<5>(); else wait_vm<0>();   // K-tile kt has landed; kt+1 (5 loads per lane) may still fly
-        s_barrier_lgkm();
+        // K-tile kt has landed for this wave: at most the 4 * min(6, nk - 1 - kt) younger loads may still fly
+        switch (min(TNS - 2, nk - 1 - kt)) {
+            case 6: wait_vm<24>(); break;
+            case 5: wait_vm<20>(); break;
+            case 4: wait_vm<16>(); break;
+            case 3: wait_vm<12>(); break;
+            case 2: wait_vm<8>(); break;
+            case 1: wait_vm<4>(); break;
+            default: wait_vm<0>(); break;
+        }
+        s_barrier_lgkm();                                   // everyone's pieces; everyone is done with the stage of K-tile kt - 1 ...
+        if (kt + TNS - 1 < nk) issue(kt + TNS - 1);         // ... which is the stage K-tile kt + 7 goes to
         if (kt == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = sbias[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+            for (int r = 0; r < 16; ++r) acc[r] = sbias[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
         }
-        const char* Ab = smem + (kt % 3) * TSTAGE;
-        const char* Bb = Ab + BOFF;
-        const bool more = kt + 2 < nk;
+        const char* Ab = smem + (kt % TNS) * TSTAGE;
+        const char* Bb = Ab + TT * TK * 2;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 wf[2], af;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int r = t * 32 + frow;
-                wf[t] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
-            }
-            const int r = wave * 32 + frow;
-            af = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
-            if (more) issue((kt + 2) % 3, (kt + 2) * TK, ks);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af, acc[j], 0, 0, 0);
+            const int rb = wn * 32 + frow, ra = wm * 32 + frow;
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 2 + hi) ^ swz(rb)) << 4));
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 2 + hi) ^ swz(ra)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc, 0, 0, 0);
         }
     }
-    // epilogue: 32 rows x 64 columns per wave, staged through stage 0 (every load has landed)
-    const int slot = lane & 7, col = n0 + slot * 8;
-    const bool col_ok = col < g.N;
-    bf16x8 rv[4];
-    if (g.res) {
+    // epilogue: the 64 x 64 tile is transposed through stage 0 (every load has landed; the barrier orders the last reads)
+    s_barrier_lgkm();
+    char* stg = smem;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int grow = m0 + wave * 32 + it * 8 + (lane >> 3);
-            if (grow < g.M && col_ok) rv[it] = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
+    for (int q4 = 0; q4 < 4; ++q4) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = acc[q4 * 4 + e];
+            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
+            else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+            v[e] = (bf16)x;
         }
+        const int row = wm * 32 + frow;
+        *reinterpret_cast<bf16x4*>(stg + row * 128 + (((wn * 4 + q4) ^ (row & 7)) << 4) + 8 * hi) = v;
     }
     s_barrier_lgkm();
-    char* stg = smem + wave * (32 * 128);
+    const int slot = tid & 7, col = n0 + slot * 8;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            bf16x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[j][q4 * 4 + e];
-                if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
-                else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-                v[e] = (bf16)x;
-            }
-            *reinterpret_cast<bf16x4*>(stg + frow * 128 + (((j * 4 + q4) ^ (frow & 7)) << 4) + 8 * hi) = v;
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const int grow = m0 + wave * 32 + row;
+    for (int it = 0; it < 2; ++it) {
+        const int row = it * 32 + (tid >> 3);
+        const int grow = m0 + row;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
-        if (grow < g.M && col_ok) {
-            if (g.res) {
+        if (grow < g.M && col < g.N && !(g.dbg & 1)) {
+            if (g.res && !(g.dbg & 2)) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[it][e]);
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rv[e]);
             }
             *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = v;
         }
@@ -417,9 +410,9 @@ int launch_tail(hipStream_t s, const PArgs& g, int act) {
         attr_set = true;
     }
     const int grid = g.tilesM * g.tilesN;
-    if (act == SETOK_ACT_NONE) gemm_tail_kernel<0><<<grid, 512, TAIL_LDS, s>>>(g);
-    else if (act == SETOK_ACT_QUICK_GELU) gemm_tail_kernel<1><<<grid, 512, TAIL_LDS, s>>>(g);
-    else gemm_tail_kernel<2><<<grid, 512, TAIL_LDS, s>>>(g);
+    if (act == SETOK_ACT_NONE) gemm_tail_kernel<0><<<grid, 256, TAIL_LDS, s>>>(g);
+    else if (act == SETOK_ACT_QUICK_GELU) gemm_tail_kernel<1><<<grid, 256, TAIL_LDS, s>>>(g);
+    else gemm_tail_kernel<2><<<grid, 256, TAIL_LDS, s>>>(g);
     SETOK_CHECK_LAUNCH("setok_linear(tail)");
     return SETOK_OK;
 }
@@ -490,6 +483,6 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (rc != SETOK_OK || p == 0) return rc;
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
-            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TM), cdiv(N, 64), dbg, nullptr, nullptr};
+            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr};
     return launch_tail(s, t, act);
 }

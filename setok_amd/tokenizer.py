@@ -374,6 +374,14 @@ class SetokTokenizer(nn.Module):
         return self.encode_features(hidden, B, k, threshold, token_mask, noise)
 
     @torch.no_grad()
+    def encode_batch(self, images: torch.Tensor, **kw):
+        """Dataset-side contract for a whole batch (pairDataset.py:419-421,445-447 call the tokenizer once per sample from
+        DataLoader workers): images (B, 3, H, W) -> (tokens, num_tokens) with tokens[i] = `gen_image` (L_i, D) of sample i and
+        num_tokens[i] = L_i (the `target_num` of preprocess_multimodal).  Bit-identical to B single-image calls (the kernels'
+        arithmetic per image does not depend on the batch), at the throughput of the batched path."""
+        feats, _, _ = self.forward(images, **kw)
+        return feats, list(feats.counts)
+
     def encode(self, image: torch.Tensor, **kw) -> torch.Tensor:
         """Dataset-side contract (pairDataset.py:419-421): one image -> tokens (L, D); L = num_tokens."""
         feats, _, _ = self.forward(image if image.dim() == 4 else image.unsqueeze(0), **kw)

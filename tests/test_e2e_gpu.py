@@ -265,3 +265,18 @@ def test_full_size_batch_invariance_and_properties():
     for j, i in enumerate(pick):
         assert torch.equal(sub_i[j], idx[i]) and torch.equal(sub_s[j], score[i])
         assert torch.equal(sub_t[j], toks[i])
+
+
+def test_dataset_side_encode_batch_equals_per_sample(golden_dir):
+    """pairDataset.py:419-447: `gen_image = vision_tokenizer(image)`, `num_tokens = gen_image.shape[0]` per sample; the batched form
+    returns the same tensors bit-exactly."""
+    z = np.load(os.path.join(golden_dir, "e2e_small.npz"))
+    sd = {k[2:]: _t(z[k]) for k in z.files if k.startswith("w:")}
+    tok = _small_tok(sd)
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(5, 3, 112, 112, generator=g).to(DEV)
+    feats, num = tok.encode_batch(images)
+    assert len(num) == 5 and all(n == feats[i].shape[0] for i, n in enumerate(num))
+    for i in range(5):
+        one = tok.encode(images[i])
+        assert one.shape[0] == num[i] and torch.equal(one, feats[i])
