@@ -175,6 +175,44 @@ int setok_splice_plan(void* stream, const int64_t* input_ids, const uint8_t* att
 int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* embed_table, int vocab, const void* image_tokens,
                       void* out, int64_t rows, int D);
 
+/* ---- training step of the trainable head --------------------------------------------------------------
+ * The reference trains through torch autograd (src/train/setok_trainer.py / train_setokim.py drive `loss.backward()`); the tower is
+ * frozen (clip_encoder.py:50, unfreeze_mm_vision_tower=False) and cluster_dpc_knn is no_grad (tokenizer.py:79), so the backward
+ * pass covers group_encoding / inter_encoder / out (tokenizer.py:147-180) and the Block / Attention / Mlp of module.py:29-100.
+ * Its GEMMs are setok_linear calls (dX = dY W: A = dY, W = W^T;  dW = dY^T X: A = dY^T, W = X^T, fp32 out); the entry points below
+ * are everything else.  All deterministic (no atomics).  `ws` arguments are caller-allocated fp32 scratch. */
+
+/* out[c * ldo + r] = x[r * ldx + c] for r < rows, c < cols; out rows are zero-filled for r in [rows, ldo) (pads the contraction
+ * dimension of the following GEMM to its K granule). */
+int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo);
+
+/* out[c] (+)= sum_r x[r, c] (bias gradients).  ws: fp32[ws_rows * cols], ws_rows >= 1 (more rows = more parallelism). */
+int setok_colsum(void* stream, int dtype, const void* x, int rows, int cols, float* out, int accumulate, float* ws, int ws_rows);
+
+/* Backward of nn.LayerNorm (module.py:81,83): dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ res], g = dy * gamma;
+ * dgamma (+)= sum_rows dy * xhat, dbeta (+)= sum_rows dy.  dx may be NULL (first layer: only the parameter gradients are needed);
+ * `accumulate` serves the norm1 shared by a Block's attention sub-layers (module.py:87-88).  ws: fp32[ws_rows * C], ws_rows >= 2. */
+int setok_layernorm_bwd(void* stream, int dtype, const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
+                        void* dx, const void* res, float* dgamma, float* dbeta, int accumulate, float* ws, int ws_rows);
+
+/* Backward of nn.GELU (exact erf, module.py:41): dx = dy * (Phi(pre) + pre * phi(pre)). */
+int setok_gelu_bwd(void* stream, int dtype, const void* pre, const void* dy, void* dx, int64_t n);
+
+/* Backward of setok_attention (module.py:61-73) over the same segments: dqkv laid out [dq | dk | dv] like qkv.
+ * out / dout: (rows, H*Dh).  ws: fp32[2 * rows * H] (log-sum-exp and do.o per row and head). */
+int setok_attention_bwd(void* stream, int dtype, const void* qkv, const int32_t* seg_offsets, int n_segs, int seg_len,
+                        const void* out, const void* dout, void* dqkv, int rows, int H, int Dh, float scale, float* ws);
+
+/* Backward of setok_segment_mean (tokenizer.py:151): drows[r, :] = dseg[s, :] / n_s for every member row r of segment s. */
+int setok_segment_mean_bwd(void* stream, int dtype, const void* dseg, const int32_t* seg_offsets, const int32_t* n_segs_dev,
+                           int max_segs, void* drows, int C);
+
+/* torch.optim.AdamW step on fp32 master parameters (decoupled weight decay, bias correction by `step` >= 1), gradient pre-scaled
+ * by grad_scale (1 / world_size after a sum all-reduce); param_lp (optional, dtype lp_dtype) receives the rounded copy the next
+ * forward uses. */
+int setok_adamw(void* stream, int lp_dtype, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_lp,
+                int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -294,3 +294,34 @@ def rac_prepare_inputs(input_ids, position_ids, attention_mask, labels, image_fe
     out = Host().prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, None, labels, images)
     _, pos, am, _, embeds, new_labels = out
     return pos, am, embeds, new_labels
+
+
+# ----------------------------------------------------------------------------------------------
+# §8(f) row 4 — parameter gradients of the reference's head modules by the reference's own autograd:
+# tokenizer.py:162-180 per image (as rac_head_single, but with gradients enabled; cluster_dpc_knn keeps its own
+# torch.no_grad, tokenizer.py:79), L = sum_i <tokens_i, upstream_i>.
+# ----------------------------------------------------------------------------------------------
+def rac_head_grads(tok, feats_list, upstream_list, k=None, threshold=None, noise_list=None):
+    tok.zero_grad(set_to_none=True)
+    for p in tok.parameters():
+        p.requires_grad_(True)
+    loss = 0.0
+    counts = []
+    for i, feats_nc in enumerate(feats_list):
+        x = feats_nc.detach().unsqueeze(0)
+        B, hw, C = x.shape
+        h = w = int(math.sqrt(hw))
+        x = x + tok.position_embedding(x.reshape(B, h, w, C)).reshape(B, hw, C)
+        x = x.squeeze(0)
+        _threshold = threshold if threshold else tok.threshold
+        _k = k if k else tok.min_cluster_num
+        with FixedNoise(None if noise_list is None else noise_list[i]):
+            index_down, idx_cluster, score = tok.cluster_dpc_knn(x, _k, None, _threshold)
+        group = tok.group_encoding(x, x[index_down, :], idx_cluster)
+        out = tok.out(tok.inter_encoder(group.unsqueeze(0)).squeeze(0))
+        counts.append(out.shape[0])
+        loss = loss + (out * upstream_list[i]).sum()
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in tok.named_parameters()
+             if p.grad is not None and not n.startswith("image_feature_encoder")}
+    return grads, counts

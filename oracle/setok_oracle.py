@@ -373,6 +373,37 @@ def encode(sd: Dict[str, Tensor], vc: VitConfig, hc: HeadConfig, images: Tensor,
 
 
 # ----------------------------------------------------------------------------------------------
+# §8(f) row 4 — gradients of the trainable head (inner_encoder, inter_encoder, out) for a training step.
+# The clustering runs under no_grad in the reference (tokenizer.py:79) and the tower is frozen (clip_encoder.py:50,
+# unfreeze_mm_vision_tower=False), so the backward pass covers a4-a6 only and stops at the head's parameters.
+# ----------------------------------------------------------------------------------------------
+HEAD_PARAM_PREFIXES = ("inner_encoder.", "inter_encoder.", "out.")
+
+
+def head_param_grads(sd: Dict[str, Tensor], hc: HeadConfig, feats: Sequence[Tensor], upstream: Sequence[Tensor], k=None,
+                     threshold=None, noise: Optional[Sequence[Tensor]] = None) -> Tuple[Dict[str, Tensor], List[HeadResult]]:
+    """d/d(theta) of  L = sum_i <tokens_i, upstream_i>  by autograd through the oracle's own forward (`head_forward`), i.e. the
+    parameter gradients a training step sees when dL/dtokens_i = upstream_i arrives from the projector / LLM.  feats[i]: (N, C) tower
+    features of image i; upstream[i]: (L_i, token_feat_dim)."""
+    params = {n: (v.detach().clone().requires_grad_(True) if n.startswith(HEAD_PARAM_PREFIXES) and ".0." not in n.split("layers.")[-1][:4]
+                  else v.detach()) for n, v in sd.items()}
+    for n in list(params):                                   # `layers.{i}.0.*` are aliases of norm1 (module.py:87-88): one shared parameter
+        if ".layers." in n and n.split(".layers.")[1].split(".")[1] == "0":
+            params[n] = params[n.split(".layers.")[0] + ".norm1." + n.split(".")[-1]]
+    loss = 0.0
+    res = []
+    for i, f in enumerate(feats):
+        r = head_forward(params, hc, f, k, threshold, None, None if noise is None else noise[i])
+        assert tuple(r.tokens.shape) == tuple(upstream[i].shape), (r.tokens.shape, upstream[i].shape)
+        loss = loss + (r.tokens * upstream[i]).sum()
+        res.append(r)
+    loss.backward()
+    grads = {n: p.grad for n, p in params.items() if p.requires_grad and p.grad is not None
+             and not (".layers." in n and n.split(".layers.")[1].split(".")[1] == "0")}      # aliases of norm1 reported once
+    return grads, res
+
+
+# ----------------------------------------------------------------------------------------------
 # a8 — mm_in_projector (src/model/multimodal_projector/builder.py:33-64) + encode_images
 #      (src/model/setokim_arch.py:206-211)
 # ----------------------------------------------------------------------------------------------

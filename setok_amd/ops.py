@@ -261,3 +261,81 @@ def splice_rows(src: Tensor, embed_table: Tensor, image_tokens: Optional[Tensor]
     _lib.call("setok_splice_rows", _stream(), _code(embed_table.dtype), _p(src), _p(embed_table), V, _p(image_tokens), _p(out),
               B * max_len, D)
     return out
+
+
+# ---- backward pass of the trainable head (csrc/backward.hip) ----------------------------------------------------------------
+def transpose(x: Tensor, pad_to: int = 1) -> Tensor:
+    """(rows, cols) -> (cols, ceil(rows / pad_to) * pad_to) with zero padding: the A / W operand of a dW = dY^T X GEMM."""
+    rows, cols = x.shape
+    assert x.is_contiguous()
+    ldo = round_up(max(rows, 1), pad_to)
+    out = torch.empty((cols, ldo), dtype=x.dtype, device=x.device)
+    _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), ldo)
+    return out
+
+
+_WS: dict = {}
+
+
+def _ws(device, n: int) -> Tensor:
+    """fp32 scratch reused across calls on the same stream (kernels of one stream run in order)."""
+    key = str(device)
+    if key not in _WS or _WS[key].numel() < n:
+        _WS[key] = torch.empty((max(n, 1 << 20),), dtype=torch.float32, device=device)
+    return _WS[key]
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+        assert not accumulate
+    ws_rows = 128
+    ws = _ws(x.device, ws_rows * cols)
+    _lib.call("setok_colsum", _stream(), _code(x.dtype), _p(x), rows, cols, _p(out), 1 if accumulate else 0, _p(ws), ws_rows)
+    return out
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float, dgamma: Tensor, dbeta: Tensor, accumulate: bool,
+                  need_dx: bool = True, res: Optional[Tensor] = None) -> Optional[Tensor]:
+    rows, Cc = x.shape
+    assert dy.shape == x.shape and dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32
+    dx = torch.empty_like(x) if need_dx else None
+    ws_rows = 2048
+    ws = _ws(x.device, ws_rows * Cc)
+    _lib.call("setok_layernorm_bwd", _stream(), _code(x.dtype), _p(x), _p(dy), _p(_f32(gamma)), eps, rows, Cc, _p(dx), _p(res),
+              _p(dgamma), _p(dbeta), 1 if accumulate else 0, _p(ws), ws_rows)
+    return dx
+
+
+def gelu_bwd(pre: Tensor, dy: Tensor) -> Tensor:
+    dx = torch.empty_like(pre)
+    _lib.call("setok_gelu_bwd", _stream(), _code(pre.dtype), _p(pre), _p(dy), _p(dx), pre.numel())
+    return dx
+
+
+def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, H: int, Dh: int, scale: float, seg_len: int,
+                  seg_offsets: Optional[Tensor] = None, n_segs: int = 0) -> Tensor:
+    rows = qkv.shape[0]
+    dqkv = torch.empty_like(qkv)
+    ws = _ws(qkv.device, 2 * rows * H)
+    _lib.call("setok_attention_bwd", _stream(), _code(qkv.dtype), _p(qkv), _p(seg_offsets), n_segs, seg_len, _p(out), _p(dout), _p(dqkv),
+              rows, H, Dh, scale, _p(ws))
+    return dqkv
+
+
+def segment_mean_bwd(dseg: Tensor, seg_offsets: Tensor, n_segs_dev: Tensor, n_segs: int, rows: int) -> Tensor:
+    Cc = dseg.shape[-1]
+    out = torch.empty((rows, Cc), dtype=dseg.dtype, device=dseg.device)
+    _lib.call("setok_segment_mean_bwd", _stream(), _code(dseg.dtype), _p(dseg), _p(seg_offsets), _p(n_segs_dev), n_segs, _p(out), Cc)
+    return out
+
+
+def adamw(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, param_lp: Optional[Tensor], lr: float, beta1: float,
+          beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+    assert param.dtype == grad.dtype == exp_avg.dtype == exp_avg_sq.dtype == torch.float32
+    n = param.numel()
+    assert grad.numel() == n and (param_lp is None or param_lp.numel() == n)
+    lp = _code(param_lp.dtype) if param_lp is not None else 0
+    _lib.call("setok_adamw", _stream(), lp, _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param_lp), n, lr, beta1, beta2, eps,
+              weight_decay, step, grad_scale)

@@ -49,7 +49,9 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int 
     large buckets (default 64 MiB) amortise launch latency without delaying the first bucket.  Returns the
     number of collectives issued."""
     world = dist.get_world_size(group)
-    grads = [p.grad for p in params if p.grad is not None]
+    # nn.Parameters contribute their .grad; plain tensors (the hand-written backward's fp32 gradient buffers) are reduced themselves
+    grads = [(p.grad if isinstance(p, torch.nn.Parameter) else p) for p in params]
+    grads = [g for g in grads if g is not None]
     n_coll, bucket, size = 0, [], 0
 
     def flush():

@@ -1,0 +1,227 @@
+"""Training step of the trainable SeTok head on the HIP library (BASELINE config 4).
+
+What is trained: `inner_encoder`, `inter_encoder`, `out` (the 37.8 M head parameters).  The tower is frozen
+(clip_encoder.py:50 with unfreeze_mm_vision_tower=False) and `cluster_dpc_knn` runs under no_grad (tokenizer.py:79), so the
+backward pass starts at dL/dtokens (what the projector / LLM hands back) and ends at the head's parameter gradients — it never
+needs dL/dfeatures.  The reference gets all of this from torch autograd; here it is written out:
+
+    forward  (saving activations)   tokenizer.py:162-180, module.py:29-100
+    backward                        out Linear <- inter_encoder Block <- segment mean <- inner_encoder Block
+    gradient all-reduce             one bucketed sum over the data-parallel group (RCCL), issued per module as soon as that
+                                    module's gradients exist, on a side stream, overlapping the rest of the backward pass
+    AdamW                           fp32 master weights, low-precision copies for the next forward
+
+Every GEMM (forward, dX = dY W, dW = dY^T X) is a `setok_linear` call; the rest is csrc/backward.hip.  No autograd, no fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .tokenizer import Block, RaggedTokens, SetokTokenizer
+
+HEAD_MODULES = ("out", "inter_encoder", "inner_encoder")          # the order their gradients become available in
+
+
+def _k_granule(dtype) -> int:
+    return 64 if dtype == torch.bfloat16 else 16                  # contraction granule of setok_linear
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Linear
+# ----------------------------------------------------------------------------------------------------------------------------
+def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[str, torch.Tensor], name: str, need_dx: bool = True,
+               residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """y = x w^T + b.  grads[name.weight] = dy^T x (fp32), grads[name.bias] = colsum(dy); returns dx = dy w (+ residual)."""
+    pad = _k_granule(x.dtype)
+    dyT, xT = ops.transpose(dy, pad), ops.transpose(x, pad)       # (N, Mp), (K, Mp): the contraction runs over the rows
+    grads[name + ".weight"] = ops.linear(dyT, xT, out_dtype=torch.float32)
+    grads[name + ".bias"] = ops.colsum(dy)
+    if not need_dx:
+        return None
+    wT = ops.transpose(w.contiguous())                            # (K, N)
+    return ops.linear(dy, wT, residual=residual)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Block (module.py:76-100): `depth` attention sub-layers sharing ONE norm1, then norm2 + Mlp
+# ----------------------------------------------------------------------------------------------------------------------------
+def block_forward_train(blk: Block, x: torch.Tensor, seg_offsets: torch.Tensor, n_segs: int, seg_bound: int):
+    pk = blk._pack()
+    H, Dh = blk.num_heads, blk.dim // blk.num_heads
+    ctx = dict(x=[], y=[], qkv=[], o=[], seg=(seg_offsets, n_segs, seg_bound))
+    for a in pk["attn"]:
+        y = ops.layernorm(x, *pk["n1"], pk["eps"])
+        qkv = ops.linear(y, a["wqkv"], a["bqkv"])
+        o = ops.attention(qkv, H, Dh, a["scale"], seg_len=seg_bound, seg_offsets=seg_offsets, n_segs=n_segs)
+        ctx["x"].append(x); ctx["y"].append(y); ctx["qkv"].append(qkv); ctx["o"].append(o)
+        x = ops.linear(o, a["wproj"], a["bproj"], residual=x)
+    y2 = ops.layernorm(x, *pk["n2"], pk["eps"])
+    pre = ops.linear(y2, pk["w1"], pk["b1"])
+    u = ops.activation(pre, ops.ACT_GELU_ERF)                     # separate from the GEMM here: the backward pass needs `pre`
+    out = ops.linear(u, pk["w2"], pk["b2"], residual=x)
+    ctx.update(xd=x, y2=y2, pre=pre, u=u)
+    return out, ctx
+
+
+def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[str, torch.Tensor], need_dx: bool) -> Optional[torch.Tensor]:
+    """g = dL/d(block output).  Fills grads[prefix + <reference parameter name>]; returns dL/d(block input) if need_dx."""
+    pk = blk._pack()
+    H, Dh = blk.num_heads, blk.dim // blk.num_heads
+    C = blk.dim
+    seg_offsets, n_segs, seg_bound = ctx["seg"]
+    dev = g.device
+    # Mlp: out = xd + fc2(gelu(fc1(norm2(xd))))
+    du = linear_bwd(ctx["u"], pk["w2"], g, grads, prefix + "mlp.fc2")
+    dpre = ops.gelu_bwd(ctx["pre"], du)
+    dy2 = linear_bwd(ctx["y2"], pk["w1"], dpre, grads, prefix + "mlp.fc1")
+    g2w = torch.empty((C,), dtype=torch.float32, device=dev); g2b = torch.empty_like(g2w)
+    g = ops.layernorm_bwd(ctx["xd"], dy2, pk["n2"][0], pk["eps"], g2w, g2b, accumulate=False, res=g)      # dL/dxd = g + LN2'(dy2)
+    grads[prefix + "norm2.weight"], grads[prefix + "norm2.bias"] = g2w, g2b
+    g1w = torch.zeros((C,), dtype=torch.float32, device=dev); g1b = torch.zeros_like(g1w)                # shared norm1 accumulates
+    depth = len(pk["attn"])
+    for i in reversed(range(depth)):
+        a = pk["attn"][i]
+        lp = prefix + f"layers.{i}.1."
+        do = linear_bwd(ctx["o"][i], a["wproj"], g, grads, lp + "proj")
+        dqkv = ops.attention_bwd(ctx["qkv"][i], ctx["o"][i], do, H, Dh, a["scale"], seg_bound, seg_offsets, n_segs)
+        dy = linear_bwd(ctx["y"][i], a["wqkv"], dqkv, grads, lp + "qkv")
+        last = i == 0 and not need_dx
+        g = ops.layernorm_bwd(ctx["x"][i], dy, pk["n1"][0], pk["eps"], g1w, g1b, accumulate=True, need_dx=not last, res=g)
+    grads[prefix + "norm1.weight"], grads[prefix + "norm1.bias"] = g1w, g1b
+    return g
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# the head
+# ----------------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, noise=None):
+    """tokenizer.py:162-180 for a batch, keeping what the backward pass needs.  Returns (tokens: RaggedTokens, ctx)."""
+    tower = tok.image_feature_encoder
+    skip = 1 if tower.select_feature == "patch" else 0
+    C = hidden_rows.shape[-1]
+    N = hidden_rows.shape[0] // B - skip
+    h = w = int(math.sqrt(N))
+    pos = tok.position_embedding.table(h, w, hidden_rows.dtype, hidden_rows.device)
+    x = ops.select_add_pos(hidden_rows, pos, B, N, skip)
+    idx, score, index_down, counts = ops.cluster_dpc_knn(x, B, N, k if k else tok.min_cluster_num,
+                                                         threshold if threshold else tok.threshold, tok.min_cluster_num, noise, None)
+    perm, seg_offsets, img_offsets = ops.cluster_sort(idx, counts)
+    counts_h = counts.cpu().tolist()
+    total = int(sum(counts_h))
+    hs = ops.gather_rows(x, perm)
+    inner_out, inner_ctx = block_forward_train(tok.inner_encoder, hs, seg_offsets, total, N)
+    group = ops.segment_mean(inner_out, seg_offsets, img_offsets[B:], total)
+    inter_out, inter_ctx = block_forward_train(tok.inter_encoder, group, img_offsets, B, max(counts_h))
+    w_out = tok.out.weight.detach().contiguous()
+    tokens = ops.linear(inter_out, w_out, tok.out.bias.detach().float().contiguous())
+    ctx = dict(inner=inner_ctx, inter=inter_ctx, inter_out=inter_out, w_out=w_out, seg_offsets=seg_offsets, img_offsets=img_offsets,
+               total=total, rows=B * N, B=B)
+    return RaggedTokens(tokens, counts_h), ctx
+
+
+@torch.no_grad()
+def head_backward(tok: SetokTokenizer, ctx, dtokens: torch.Tensor, on_module_done: Optional[Callable[[str, Dict[str, torch.Tensor]], None]] = None
+                  ) -> Dict[str, torch.Tensor]:
+    """dtokens: (sum L_i, token_feat_dim) = dL/dtokens in the packed order of the forward's RaggedTokens.  Returns fp32 gradients
+    under the reference's parameter names.  `on_module_done(module, grads_of_that_module)` fires as soon as a module's gradients
+    are complete (out, then inter_encoder, then inner_encoder) — the hook the overlapped all-reduce hangs on."""
+    grads: Dict[str, torch.Tensor] = {}
+
+    def done(mod):
+        if on_module_done is not None:
+            on_module_done(mod, {n: g for n, g in grads.items() if n.startswith(mod + ".")})
+
+    dtokens = dtokens.to(ctx["inter_out"].dtype).contiguous()
+    g = linear_bwd(ctx["inter_out"], ctx["w_out"], dtokens, grads, "out")
+    done("out")
+    g = block_backward(tok.inter_encoder, "inter_encoder.", ctx["inter"], g, grads, need_dx=True)
+    done("inter_encoder")
+    g = ops.segment_mean_bwd(g, ctx["seg_offsets"], ctx["img_offsets"][ctx["B"]:], ctx["total"], ctx["rows"])
+    block_backward(tok.inner_encoder, "inner_encoder.", ctx["inner"], g, grads, need_dx=False)
+    done("inner_encoder")
+    return grads
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# optimizer + data-parallel step
+# ----------------------------------------------------------------------------------------------------------------------------
+class HeadTrainer:
+    """AdamW over the head's parameters with fp32 master weights, and the data-parallel training step:
+
+        tokens, ctx = trainer.forward(images)             # tower (frozen) + head, activations kept
+        trainer.backward(ctx, dtokens)                    # gradients; per-module all-reduce overlapped on a side stream
+        trainer.step()                                    # waits for the all-reduce, AdamW, refreshes the low-precision weights
+    """
+
+    def __init__(self, tok: SetokTokenizer, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, process_group=None, bucket_bytes: int = 64 << 20):
+        self.tok = tok
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.group = process_group
+        self.bucket_bytes = bucket_bytes
+        self.t = 0
+        self.params: Dict[str, torch.nn.Parameter] = {n: p for n, p in tok.named_parameters() if n.split(".")[0] in HEAD_MODULES}
+        self.master = {n: p.detach().float().clone() for n, p in self.params.items()}
+        self.m = {n: torch.zeros_like(v) for n, v in self.master.items()}
+        self.v = {n: torch.zeros_like(v) for n, v in self.master.items()}
+        self.grads: Dict[str, torch.Tensor] = {}
+        self._comm_stream = None
+        self._pending: List = []
+
+    # -- data-parallel plumbing --------------------------------------------------------------------------------------------
+    @property
+    def world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _allreduce_module(self, mod: str, g: Dict[str, torch.Tensor]) -> None:
+        """Sum-all-reduce one module's gradients as flat buckets on the communication stream (RCCL over xGMI: point-to-point links,
+        a ring is per-link bound, so few large buckets), while the compute stream carries on with the next module's backward."""
+        if self.world == 1 or not g:
+            return
+        import torch.distributed as dist
+        from .parallel import allreduce_gradients
+        names = sorted(g)
+        if g[names[0]].is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                allreduce_gradients([g[n] for n in names], group=self.group, bucket_bytes=self.bucket_bytes, average=False)
+                ev = torch.cuda.Event(); ev.record(self._comm_stream)
+            self._pending.append(ev)
+        else:
+            allreduce_gradients([g[n] for n in names], group=self.group, bucket_bytes=self.bucket_bytes, average=False)
+
+    # -- the step -------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, k=None, threshold=None, noise=None):
+        B = images.shape[0]
+        hidden = self.tok.image_feature_encoder.hidden_rows(images)
+        if hidden.dtype != self.tok.dtype:
+            hidden = hidden.to(self.tok.dtype)
+        return head_forward_train(self.tok, hidden, B, k, threshold, noise)
+
+    @torch.no_grad()
+    def backward(self, ctx, dtokens: torch.Tensor) -> Dict[str, torch.Tensor]:
+        self._pending = []
+        self.grads = head_backward(self.tok, ctx, dtokens, on_module_done=self._allreduce_module)
+        return self.grads
+
+    @torch.no_grad()
+    def step(self) -> None:
+        for ev in self._pending:
+            torch.cuda.current_stream().wait_event(ev)
+        self._pending = []
+        self.t += 1
+        scale = 1.0 / self.world                                      # mean over the data-parallel ranks
+        for n, p in self.params.items():
+            ops.adamw(self.master[n].view(-1), self.grads[n].reshape(-1), self.m[n].view(-1), self.v[n].view(-1), p.data.view(-1), self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.wd, self.t, scale)
+        self.tok.inner_encoder._packed = {}                          # the packed fp32 biases / LayerNorm affines are copies: re-read them
+        self.tok.inter_encoder._packed = {}

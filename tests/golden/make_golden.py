@@ -256,12 +256,42 @@ def gen_splice():
     save("splice", **arrs)
 
 
+# ----------------------------------------------------------------------------------------------
+def gen_head_grads():
+    """§8(f) row 4: parameter gradients of the reference's head modules by the reference's OWN autograd
+    (oracle/rac_harness.py::rac_head_grads) for L = sum_i <tokens_i, upstream_i> on the two dynamic-k images of head_small.npz
+    (whose weights and features it reuses).  Stored: the upstream gradients and every parameter gradient."""
+    z = np.load(os.path.join(HERE, "head_small.npz"))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    tok = small_tok()
+    res = tok.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    feats = [torch.from_numpy(z["dynamic:feats"]), torch.from_numpy(z["planted:feats"])]
+    thr = float(z["dynamic:threshold"])
+    hc = O.HeadConfig(hidden_dim=64, token_feat_dim=96, min_cluster_num=8, threshold=0.5, nheads=2, dim_feedforward=128)
+    with torch.no_grad():
+        Ls = [O.head_forward(sd, hc, f, None, thr).tokens.shape[0] for f in feats]
+    g = torch.Generator().manual_seed(0)
+    ups = [torch.randn(L, 96, generator=g) for L in Ls]
+    grads, counts = R.rac_head_grads(tok, feats, ups, threshold=thr)
+    assert counts == Ls
+    arrs = {"threshold": np.array(thr), "counts": np.array(Ls)}
+    for i, u in enumerate(ups):
+        arrs[f"up:{i}"] = npy(u)
+    for n, v in grads.items():
+        arrs["g:" + n] = npy(v)
+    print("head grads:", len(grads), "tensors, token counts", Ls)
+    save("head_grads", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice"]
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads"]
     if "detok" in which:
         gen_detok()
     if "splice" in which:
         gen_splice()
+    if "head_grads" in which:
+        gen_head_grads()
     if "head_small" in which:
         gen_head_small()
     if "cluster_full" in which:

@@ -245,3 +245,21 @@ def test_splice_needs_enough_images():
     ids, am, labels, feats, W = O.splice_inputs(7, 4, 10, 30, 8)
     with pytest.raises(IndexError):
         O.splice_multimodal(ids, None, am, labels, feats[:-1], W)
+
+
+# ---- §8(f) row 4: gradients of the trainable head ----------------------------------------------------------------------
+def test_head_param_grads_match_reference_autograd(golden_dir):
+    """oracle.head_param_grads (autograd through the oracle's forward) against the gradients the REFERENCE's modules produce
+    under the reference's own autograd (tests/golden/head_grads.npz)."""
+    z = _load(golden_dir, "head_small")
+    gz = _load(golden_dir, "head_grads")
+    sd = {k[2:]: _t(z[k]) for k in z.files if k.startswith("w:")}
+    hc = O.HeadConfig(hidden_dim=64, token_feat_dim=96, min_cluster_num=8, threshold=0.5, nheads=2, dim_feedforward=128)
+    feats = [_t(z["dynamic:feats"]), _t(z["planted:feats"])]
+    ups = [_t(gz["up:0"]), _t(gz["up:1"])]
+    grads, res = O.head_param_grads(sd, hc, feats, ups, threshold=float(gz["threshold"]))
+    assert [r.tokens.shape[0] for r in res] == gz["counts"].tolist()
+    names = [k[2:] for k in gz.files if k.startswith("g:")]
+    assert set(names) == set(grads) and len(names) == 34
+    for n in names:
+        torch.testing.assert_close(grads[n], _t(gz["g:" + n]), rtol=1e-5, atol=1e-6)
