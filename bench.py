@@ -48,6 +48,10 @@ WORKLOADS = {
                                "1024/2 heads/ff 4096 -> 4096, mm_in_projector mlp2x_gelu; encode-only"),
     "cfg4-forward": (336, 128, False, "cfg4 shapes, FORWARD ONLY (the training step is not built): ViT-L/14 336^2 = 576 patches, dyn-k, batch 128 "
                                        "per GPU, same head and projector as cfg2"),
+    "cfg4": (336, 128, False, "cfg4: ViT-L/14 336^2 = 576 patches (tower frozen), dyn-k, batch 128 per GPU; TRAINING STEP of the head (37.8 M "
+                               "parameters: inner_encoder, inter_encoder, out): tower + head forward with saved activations, hand-written backward "
+                               "from a synthetic dL/dtokens, per-module RCCL gradient all-reduce overlapped with the backward pass, AdamW on fp32 "
+                               "master weights"),
     "cfg3": (224, 256, True, "cfg3: cfg2 encode + reconstruction decoder (SetokDeTokenizer: token_feat_dim 4096 -> Q-Former 768/12 heads/6 layers, "
                               "324 queries (image_size 256 / 14), cross-attention every 2nd layer -> 16 x ViT block 768/16 heads -> LayerNorm); "
                               "no loss (the reference's GANLoss path is out of scope)"),
@@ -186,7 +190,17 @@ def main():
     g = torch.Generator().manual_seed(3 + rank)
     images = torch.randn(B, 3, img, img, generator=g).to(device=dev, dtype=torch.bfloat16)   # resident in HBM
 
+    trainer = None
+    if args.workload == "cfg4":
+        from setok_amd.training import HeadTrainer
+        trainer = HeadTrainer(tok, lr=1e-5, weight_decay=0.0)
+
     def step():
+        if trainer is not None:
+            tokens, ctx = trainer.forward(images)
+            trainer.backward(ctx, tokens.packed * 1e-3)          # dL/dtokens of L = 5e-4 |tokens|^2, standing in for the projector / LLM
+            trainer.step()
+            return tokens
         if det is None:
             return setok_amd.encode_images(tok, proj, images)
         tokens, _, _ = tok(images)                   # SeTok.forward (src/model/setok/model.py:87-88): tokenize, then detokenize

@@ -183,8 +183,10 @@ int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* e
  * are everything else.  All deterministic (no atomics).  `ws` arguments are caller-allocated fp32 scratch. */
 
 /* out[c * ldo + r] = x[r * ldx + c] for r < rows, c < cols; out rows are zero-filled for r in [rows, ldo) (pads the contraction
- * dimension of the following GEMM to its K granule). */
-int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo);
+ * dimension of the following GEMM to its K granule).  chunk > 0 (a divisor of ldo): the padded row range is cut into ldo / chunk
+ * pieces stored one after the other, each a (cols, chunk) matrix — the operand layout of a split-K batched dW GEMM whose
+ * fp32 partial products are then summed in a fixed order (setok_colsum over the batch). */
+int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int chunk);
 
 /* out[c] (+)= sum_r x[r, c] (bias gradients).  ws: fp32[ws_rows * cols], ws_rows >= 1 (more rows = more parallelism). */
 int setok_colsum(void* stream, int dtype, const void* x, int rows, int cols, float* out, int accumulate, float* ws, int ws_rows);

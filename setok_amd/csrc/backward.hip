@@ -9,10 +9,12 @@
 
 namespace {
 
-// ---- out[c * ldo + r] = x[r * ldx + c]; rows r in [rows, ldo) of the output are written as zeros -------------------------------
+// ---- out[c * ldo + r] = x[r * ldx + c]; rows r in [rows, ldo) of the output are written as zeros.  With chunk > 0 the padded row
+//      range is cut into ldo / chunk chunks stored one after the other, each as a (cols, chunk) matrix: the split-K operand layout of
+//      a batched dW GEMM (out[((r / chunk) * cols + c) * chunk + r % chunk]) ---------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, int64_t ldx, int rows, int cols, T* __restrict__ out,
-                                                        int64_t ldo) {
+                                                        int64_t ldo, int chunk) {
     __shared__ T tile[64][65];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -23,7 +25,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
-        if (c < cols && r < ldo) out[(int64_t)c * ldo + r] = tile[tx][i];
+        if (c < cols && r < ldo) {
+            if (chunk > 0) out[((int64_t)(r / chunk) * cols + c) * chunk + r % chunk] = tile[tx][i];
+            else out[(int64_t)c * ldo + r] = tile[tx][i];
+        }
     }
 }
 
@@ -333,15 +338,16 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     else if (dtype == SETOK_F32) { CALL_F32; }                                 \
     else return setok_fail(SETOK_EINVAL, NAME ": bad dtype %d", dtype);
 
-extern "C" int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo) {
+extern "C" int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int chunk) {
     SETOK_CHECK_ARG(x && out, "setok_transpose: null operand");
     SETOK_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols && ldo >= rows, "setok_transpose: bad shape rows=%d cols=%d ldx=%lld ldo=%lld", rows, cols,
                     (long long)ldx, (long long)ldo);
+    SETOK_CHECK_ARG(chunk == 0 || (chunk > 0 && ldo % chunk == 0), "setok_transpose: ldo=%lld is not a multiple of chunk=%d", (long long)ldo, chunk);
     if (ldo == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv((int)ldo, 64), cdiv(cols, 64));
-    DISPATCH_T("setok_transpose", (transpose_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, ldx, rows, cols, (bf16*)out, ldo)),
-               (transpose_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ldx, rows, cols, (float*)out, ldo)));
+    DISPATCH_T("setok_transpose", (transpose_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, ldx, rows, cols, (bf16*)out, ldo, chunk)),
+               (transpose_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ldx, rows, cols, (float*)out, ldo, chunk)));
     SETOK_CHECK_LAUNCH("setok_transpose");
     return SETOK_OK;
 }
@@ -371,7 +377,7 @@ extern "C" int setok_layernorm_bwd(void* stream, int dtype, const void* x, const
     hipStream_t s = (hipStream_t)stream;
     int nb = cdiv(rows, 4);
     if (nb > ws_rows / 2) nb = ws_rows / 2;
-    if (nb > 1024) nb = 1024;
+    if (nb > 256) nb = 256;
     float* pg = ws; float* pb = ws + (int64_t)nb * C;
     const size_t smem = (size_t)8 * C * sizeof(float);
     SETOK_CHECK_ARG(smem <= 64 * 1024, "setok_layernorm_bwd: C too large");

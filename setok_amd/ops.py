@@ -264,13 +264,36 @@ def splice_rows(src: Tensor, embed_table: Tensor, image_tokens: Optional[Tensor]
 
 
 # ---- backward pass of the trainable head (csrc/backward.hip) ----------------------------------------------------------------
-def transpose(x: Tensor, pad_to: int = 1) -> Tensor:
-    """(rows, cols) -> (cols, ceil(rows / pad_to) * pad_to) with zero padding: the A / W operand of a dW = dY^T X GEMM."""
+def transpose(x: Tensor, pad_to: int = 1, splits: int = 1) -> Tensor:
+    """(rows, cols) -> (cols, P) with P = rows zero-padded to a multiple of pad_to: the A / W operand of a dW = dY^T X GEMM.
+    splits > 1: P is padded to splits * chunk (chunk a multiple of pad_to) and the result is (splits, cols, chunk) — the split-K layout."""
     rows, cols = x.shape
     assert x.is_contiguous()
-    ldo = round_up(max(rows, 1), pad_to)
-    out = torch.empty((cols, ldo), dtype=x.dtype, device=x.device)
-    _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), ldo)
+    if splits <= 1:
+        ldo = round_up(max(rows, 1), pad_to)
+        out = torch.empty((cols, ldo), dtype=x.dtype, device=x.device)
+        _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), ldo, 0)
+        return out
+    chunk = round_up((max(rows, 1) + splits - 1) // splits, pad_to)
+    out = torch.empty((splits, cols, chunk), dtype=x.dtype, device=x.device)
+    _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), splits * chunk, chunk)
+    return out
+
+
+def linear_tn(aT: Tensor, bT: Tensor) -> Tensor:
+    """dW = sum_s aT[s] @ bT[s]^T in fp32 for split-K operands aT (S, N, chunk), bT (S, K, chunk) from `transpose(..., splits=S)`
+    (or 2-D (N, P), (K, P) for S = 1): one batched GEMM for the partial products, then a fixed-order sum over the splits."""
+    if aT.dim() == 2:
+        return linear(aT, bT, out_dtype=torch.float32)
+    S, N, chunk = aT.shape
+    S2, K, chunk2 = bT.shape
+    assert S == S2 and chunk == chunk2 and aT.dtype == bT.dtype
+    part = torch.empty((S, N, K), dtype=torch.float32, device=aT.device)
+    _lib.call("setok_linear", _stream(), _code(aT.dtype), F32, _p(aT), chunk, _p(bT), None, None, _p(part), K, N, K, chunk, ACT_NONE, S,
+              N * chunk, K * chunk, N * K)
+    out = torch.empty((N, K), dtype=torch.float32, device=aT.device)
+    ws = _ws(aT.device, N * K)
+    _lib.call("setok_colsum", _stream(), F32, _p(part), S, N * K, _p(out), 0, _p(ws), 1)
     return out
 
 

@@ -37,8 +37,13 @@ def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[s
                residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """y = x w^T + b.  grads[name.weight] = dy^T x (fp32), grads[name.bias] = colsum(dy); returns dx = dy w (+ residual)."""
     pad = _k_granule(x.dtype)
-    dyT, xT = ops.transpose(dy, pad), ops.transpose(x, pad)       # (N, Mp), (K, Mp): the contraction runs over the rows
-    grads[name + ".weight"] = ops.linear(dyT, xT, out_dtype=torch.float32)
+    M, N, K = x.shape[0], dy.shape[1], x.shape[1]
+    # the contraction runs over the M rows; a weight gradient has few output tiles (N x K), so long contractions are split into S
+    # batched partial products summed in a fixed order — enough workgroups to fill the chip, still deterministic
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    S = max(1, min(16, 1024 // max(tiles, 1), M // 2048))
+    dyT, xT = ops.transpose(dy, pad, S), ops.transpose(x, pad, S)
+    grads[name + ".weight"] = ops.linear_tn(dyT, xT)
     grads[name + ".bias"] = ops.colsum(dy)
     if not need_dx:
         return None

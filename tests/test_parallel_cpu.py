@@ -51,6 +51,15 @@ def _worker(rank, world, port, q):
         assert ncoll >= 2
         for i, p in enumerate(params):
             assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * (1 + world) / 2.0))
+        # 3b. the training step's per-module reduction: plain fp32 gradient tensors (the hand-written backward's buffers), summed
+        #     over ranks (HeadTrainer divides by the world size inside AdamW), through the trainer's own hook
+        from setok_amd.training import HeadTrainer
+        tr = HeadTrainer.__new__(HeadTrainer)
+        tr.group, tr.bucket_bytes, tr._comm_stream, tr._pending = None, 4096, None, []
+        gmod = {"out.weight": torch.full((300, 7), float(rank + 1)), "out.bias": torch.full((300,), 10.0 * (rank + 1))}
+        tr._allreduce_module("out", gmod)
+        assert torch.allclose(gmod["out.weight"], torch.full((300, 7), 3.0)) and torch.allclose(gmod["out.bias"], torch.full((300,), 30.0))
+        assert tr.world == world
         # 4. timing rule
         assert P.max_over_ranks(1.0 + rank) == float(world)
         q.put((rank, "ok"))

@@ -44,6 +44,20 @@ def test_transpose_pads_with_zeros(dt, rows, cols, pad):
     assert out.shape == (cols, ldo) and torch.equal(out[:, :rows], x.t()) and float(out[:, rows:].abs().max() if ldo > rows else 0) == 0.0
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-5)])
+@pytest.mark.parametrize("M,N,K,S", [(5000, 96, 64, 4), (20000, 256, 128, 8), (700, 64, 64, 3)])
+def test_split_k_weight_gradient(dt, tol, M, N, K, S):
+    """dW = dY^T X through the split-K layout (chunked transposes, one batched GEMM, fixed-order sum) == the plain product."""
+    dy, x = _rand(M, N, seed=20).to(dt), _rand(M, K, seed=21).to(dt)
+    pad = 64 if dt == torch.bfloat16 else 16
+    aT, bT = ops.transpose(dy.to(DEV), pad, S), ops.transpose(x.to(DEV), pad, S)
+    assert aT.shape[0] == S and aT.shape[1] == N and aT.shape[2] % pad == 0
+    got = ops.linear_tn(aT, bT)
+    assert got.dtype == torch.float32 and _rel(got, dy.double().t() @ x.double()) < tol
+    again = ops.linear_tn(aT, bT)
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-5)])
 def test_colsum_and_accumulate(dt, tol):
     x = _rand(3000, 200, seed=2).to(dt)
