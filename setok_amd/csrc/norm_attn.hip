@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const T* __restrict__ 
 }
 
 int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, int Dh, float scale);  // attn_vit.hip
+int setok_attention_seg_bf16(hipStream_t s, const bf16* qkv, const int32_t* seg_offsets, int n_segs, int max_len, bf16* out, int rows, int H, int Dh, float scale);  // attn_seg.hip
 int setok_cross_attention_bf16(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const bf16* v, int64_t ldkv, const int32_t* kv_offsets,
                                int n_segs, int q_len, int max_kv, bf16* out, int64_t ldo, int H, float scale);           // attn_vit.hip
 
@@ -187,6 +188,10 @@ extern "C" int setok_attention(void* stream, int dtype, const void* qkv, const i
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SETOK_BF16 && !seg_offsets && (Dh == 64 || Dh == 48) && rows % seg_len == 0) {
         const int rc = setok_attention_vit_bf16(s, (const bf16*)qkv, (bf16*)out, rows / seg_len, seg_len, H, Dh, scale);
+        if (rc != SETOK_EUNSUPPORTED) return rc;
+    }
+    if (dtype == SETOK_BF16 && seg_offsets && Dh == 512) {
+        const int rc = setok_attention_seg_bf16(s, (const bf16*)qkv, seg_offsets, n_segs, seg_len, (bf16*)out, rows, H, Dh, scale);
         if (rc != SETOK_EUNSUPPORTED) return rc;
     }
     const size_t smem = (size_t)(Dh + seg_len) * sizeof(float);

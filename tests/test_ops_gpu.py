@@ -196,6 +196,20 @@ def test_cross_attention_uniform_and_errors():
         ops.cross_attention(q.to(DEV), kvd[:, :C], kvd[:, C:], H, Dh, 0.3, 0, None, B, L)
 
 
+@pytest.mark.parametrize("lens", [[1, 7, 64, 3, 1, 129, 20], [5] * 40, [33, 32, 31, 1, 2, 300]])
+def test_attention_ragged_head_dim_512_bf16(lens):
+    """The SeTok head's shape (2 heads x 512) over ragged segments: the segment-owning MFMA kernel (attn_seg.hip)."""
+    H, Dh = 2, 512
+    offs = np.concatenate([[0], np.cumsum(lens)]).tolist()
+    qkv = (_rand(offs[-1], 3 * H * Dh, seed=31) * 0.5).bfloat16()
+    ref = _attn_ref(qkv, H, Dh, Dh ** -0.5, offs)
+    so = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    got = ops.attention(qkv.to(DEV), H, Dh, Dh ** -0.5, seg_len=max(lens), seg_offsets=so, n_segs=len(lens))
+    assert _rel_err(got, ref) < 1e-2
+    again = ops.attention(qkv.to(DEV), H, Dh, Dh ** -0.5, seg_len=max(lens), seg_offsets=so, n_segs=len(lens))
+    assert torch.equal(got, again)
+
+
 # ---------------------------------------------------------------------------------------------
 # glue
 # ---------------------------------------------------------------------------------------------
