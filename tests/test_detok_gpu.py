@@ -104,3 +104,20 @@ def test_detokenizer_errors():
         det(torch.zeros(2, 3, 16, device=DEV))
     with pytest.raises(ValueError):
         det(torch.zeros(2, 3, 32, device=DEV), torch.tensor([[1, 1, 0], [0, 0, 0]], device=DEV))
+
+
+def test_detokenizer_full_dims_batch_invariance_bf16():
+    """cfg3 dims (token_feat_dim 4096 -> Q-Former 768 / 12 heads / 6 layers, 324 queries, 16 ViT blocks of 768 / 16 heads), bf16, 24 images
+    with ~36 tokens each: an image decoded alone is bit-identical to the same image inside the batch, and two runs are bit-identical."""
+    det = SetokDeTokenizer(token_feat_dim=4096, hidden_dim=768, patch_size=14, image_size=256, decoder_embed_dim=768, decoder_nheads=16,
+                           decoder_depth=16).to(device=DEV, dtype=torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(4)
+    counts = [int(c) for c in torch.randint(24, 56, (24,), generator=g)]
+    toks = [torch.randn(c, 4096, generator=g).to(device=DEV, dtype=torch.bfloat16) for c in counts]
+    full = det(toks)
+    assert tuple(full.shape) == (24, 324, 768) and bool(torch.isfinite(full.float()).all())
+    assert torch.equal(full, det(toks))
+    for i in (0, 7, 23):
+        assert torch.equal(det([toks[i]])[0], full[i]), i
+    sub = det(toks[5:9])
+    assert torch.equal(sub, full[5:9])

@@ -216,3 +216,29 @@ def test_training_step_bf16_runs_and_reduces_loss():
         tr.backward(ctx, (2.0 * diff / diff.numel()).to(torch.bfloat16))
         tr.step()
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_training_step_full_dims_deterministic_bf16():
+    """cfg4 head dims (1024 / 2 heads / ff 4096 -> 4096, 576 patches) in bf16 on 6 images: forward + backward twice from the same state give
+    bit-identical gradients (no atomics, fixed reduction orders, split-K partials summed in a fixed order), all finite, none identically zero
+    except the key biases (whose gradient is exactly 0: softmax is shift-invariant)."""
+    C, N, B = 1024, 576, 6
+    vc = dict(hidden_size=C, intermediate_size=4096, num_hidden_layers=1, num_attention_heads=16, image_size=336, patch_size=14)
+    tok = SetokTokenizer(vision_tower=vc, mm_vision_select_layer=-1, hidden_dim=C, token_feat_dim=4096, min_cluster_num=64,
+                         threshold=0.125, nheads=2, dim_feedforward=4096).to(device=DEV, dtype=torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(1)
+    hidden = torch.randn(B * (N + 1), C, generator=g).to(device=DEV, dtype=torch.bfloat16)
+    tokens, ctx = head_forward_train(tok, hidden, B)
+    up = (tokens.packed.float() * 1e-2).to(torch.bfloat16)
+    g1 = head_backward(tok, ctx, up)
+    tokens2, ctx2 = head_forward_train(tok, hidden, B)
+    g2 = head_backward(tok, ctx2, up)
+    assert torch.equal(tokens.packed, tokens2.packed)
+    assert len(g1) == 34
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+        assert bool(torch.isfinite(g1[n]).all()), n
+        if not n.endswith("qkv.bias"):
+            assert float(g1[n].abs().max()) > 0, n
+    kb = g1["inner_encoder.layers.0.1.qkv.bias"][C:2 * C]
+    assert float(kb.abs().max()) <= 1e-2 * float(g1["inner_encoder.layers.0.1.qkv.bias"].abs().max())
