@@ -457,9 +457,10 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     int p = 0;
     const int T = tilesM * tilesN, r = T % ncu;
     if (T > ncu && r != 0 && r % tilesN == 0 && r / tilesN <= 2) p = r / tilesN;
-    const int tm_main = tilesM - p;
     static const int dbg = [] { const char* e = getenv("SETOK_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     if (dbg & 4) p = 0;
+    if (dbg & 8) p = tilesM;                                        // experiment: everything through the deep-pipeline 64x64 kernel
+    const int tm_main = tilesM - p;
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
@@ -469,7 +470,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
         if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
         g.zero_bias = zb;
     }
-    int rc = launch_main(s, g, act, ncu);
+    int rc = (tilesM - p) > 0 ? launch_main(s, g, act, ncu) : SETOK_OK;
     if (timing && tim) {
         unsigned long long h[256 * 4];
         if (hipMemcpy(h, tim, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
