@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                             bf16* C, int64_t ldc, int M, int N, int K, int act);    // gemm_persist.hip
+int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
+                                   int64_t sA, int64_t sW, int64_t sC);               // gemm_persist.hip
 
 // --------------------------------------------------------------------------------------------
 // fp32 64x64x16  (exact f32 MFMA; parity mode)
@@ -242,6 +244,10 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
         // big problems (>= 96 tiles of 256x256): persistent direct-to-LDS kernel (gemm_persist.hip)
         if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 96 && !g_force_small_tiles)
             return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
+        // fp32-out batched problems without bias / activation / residual and with enough tiles (weight-gradient partial products)
+        if (out_dtype == SETOK_F32 && !bias && !residual && act == SETOK_ACT_NONE && N % 64 == 0 && K >= 192 && ldc % 4 == 0 &&
+            strideA % 8 == 0 && strideW % 8 == 0 && strideC % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) * batch >= 96 && !g_force_small_tiles)
+            return setok_gemm_persist_f32_batched(s, (const bf16*)A, lda, (const bf16*)W, (float*)C, ldc, M, N, K, batch, strideA, strideW, strideC);
         dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
         if (out_dtype == SETOK_BF16) gemm_bf16_kernel<bf16, true><<<grid, 256, 0, s>>>(g);
         else if (out_dtype == SETOK_F32) gemm_bf16_kernel<float, false><<<grid, 256, 0, s>>>(g);

@@ -39,6 +39,9 @@ struct PArgs {
     int M, N, K, tilesM, tilesN, dbg;
     unsigned long long* tim;     // debug: per-block {main-loop, epilogue, wait-at-first-ktile} cycle sums
     const float* zero_bias;      // 64 zeros: a null bias is scalar-loaded like a real one
+    float* Cf;                   // F32B variant: fp32 output, `nbatch` independent problems (split-K partial products of a weight gradient)
+    int64_t sA, sW, sC;          //   element strides between the batch members
+    int nbatch;
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -68,7 +71,10 @@ __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) 
 constexpr int MAIN_LDS = 2 * STAGE + 8 * 4096;   // 163840: all of the CU's LDS
 __device__ float kZeroBias[64];                    // stands in for a null bias (scalar-loaded like a real one)
 
-template <int ACT>
+// F32B = false: the bf16-out kernel of every large Linear.  F32B = true: fp32 output written straight from the accumulators (the outputs
+// are weight-gradient sized, store efficiency is irrelevant) for a BATCH of problems sharing M, N, K — the split-K partial products of
+// dW = dY^T X (training.py), which by themselves have too few output tiles to fill the chip.
+template <int ACT, bool F32B>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     constexpr int WNC = 4, WR = 128, MI = 4, TNB = 256;
     constexpr int NL = 8;                          // LDS-DMA ops per lane per K-tile
@@ -80,15 +86,19 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     const int wm = wave / WNC, wn = wave % WNC;
     const int frow = lane & 31, hi = lane >> 5;
     const int nk = g.K / TK;
-    const int num_tiles = g.tilesM * g.tilesN;
+    const int tiles_per_problem = g.tilesM * g.tilesN;
+    const int num_tiles = tiles_per_problem * (F32B ? g.nbatch : 1);
     const int G = gridDim.x;
+    int bz = 0, nbz = 0;                           // batch member of the current / next tile (F32B)
 
     // tile id for (round, block): XCD x (= blockIdx % 8) owns 32 consecutive ids per round = an 8 (M) x 4 (N) patch
-    auto tile_of = [&](int round, int& m0, int& n0) -> bool {
+    auto tile_of = [&](int round, int& m0, int& n0, int& b) -> bool {
         int L;
         if ((G & 7) == 0) L = round * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
         else L = round * G + blockIdx.x;
         if (L >= num_tiles) return false;
+        b = 0;
+        if (F32B) { b = L / tiles_per_problem; L -= b * tiles_per_problem; }
         constexpr int GM = 8;
         const int per = GM * g.tilesN, group = L / per, first_m = group * GM;
         const int gm = min(g.tilesM - first_m, GM), in = L - group * per;
@@ -98,12 +108,14 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     };
 
     const bf16* a_src[4]; const bf16* b_src[4];
-    auto set_src = [&](int m0, int n0) {
+    auto set_src = [&](int m0, int n0, int b) {
+        const bf16* Ab_ = F32B ? g.A + (int64_t)b * g.sA : g.A;
+        const bf16* Wb_ = F32B ? g.W + (int64_t)b * g.sW : g.W;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
-            a_src[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-            b_src[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
+            a_src[i] = Ab_ + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+            b_src[i] = Wb_ + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
         }
     };
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
@@ -121,8 +133,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     };
 
     int m0, n0, round = 0;
-    if (!tile_of(0, m0, n0)) return;
-    set_src(m0, n0);
+    if (!tile_of(0, m0, n0, bz)) return;
+    set_src(m0, n0, bz);
     issue_ktile(0, 0);
     issue_ktile(1, TK);
     int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     for (;;) {
         const unsigned long long ts0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
         int nm0 = 0, nn0 = 0;
-        const bool has_next = tile_of(round + 1, nm0, nn0);
+        const bool has_next = tile_of(round + 1, nm0, nn0, nbz);
 
         // ---- accumulators start at the bias (fp32, added before the single bf16 rounding): scalar loads.  N % 64 == 0
         //      (dispatch condition), so a wave's 64 columns are all inside or all outside the matrix ---------------------
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             }
         };
         s_barrier_lgkm();
-        if (has_next) set_src(nm0, nn0);                                           // addresses first, loads after: no reload lands behind a DMA
+        if (has_next) set_src(nm0, nn0, nbz);                                      // addresses first, loads after: no reload lands behind a DMA
         if (use_res) { if (interior) load_residual(yes{}, 0); else load_residual(no{}, 0); }
         multiply(yes{}, has_next, 0);                                              // last K-tile; the next tile's first one goes out
         const unsigned long long ts1 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
@@ -280,12 +292,34 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                 }
             }
         };
-        if (use_res) { if (interior) epilogue(yes{}, yes{}); else epilogue(yes{}, no{}); }
-        else { if (interior) epilogue(no{}, yes{}); else epilogue(no{}, no{}); }
+        if constexpr (F32B) {
+            // fp32 out: a lane holds, for output row frow of each 32-row tile, 4 consecutive columns per accumulator quad -> 16-byte stores
+            if (has_next) issue_ktile((cnt + 1) & 1, TK);
+            float* Cb = g.Cf + (int64_t)bz * g.sC;
+#pragma unroll
+            for (int h = 0; h < MI; ++h) {
+                const int grow = m0 + wm * WR + h * 32 + frow;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int c = n0 + wn * 64 + j * 32 + q4 * 8 + 4 * hi;
+                        if (grow < g.M && c < g.N) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[h][j][q4 * 4 + e];
+                            *reinterpret_cast<f32x4*>(Cb + (int64_t)grow * g.ldc + c) = v;
+                        }
+                    }
+            }
+        } else {
+            if (use_res) { if (interior) epilogue(yes{}, yes{}); else epilogue(yes{}, no{}); }
+            else { if (interior) epilogue(no{}, yes{}); else epilogue(no{}, no{}); }
+        }
         if (g.tim) { const unsigned long long ts2 = __builtin_amdgcn_s_memtime(); t_main += ts1 - ts0; t_epi += ts2 - ts1; }
         if (!has_next) break;
-        pend = interior ? NSTORE : -1;
-        m0 = nm0; n0 = nn0; ++round;
+        pend = (interior && !F32B) ? NSTORE : -1;
+        m0 = nm0; n0 = nn0; bz = nbz; ++round;
     }
     if (g.tim && tid == 0) { g.tim[blockIdx.x * 4 + 0] = t_main; g.tim[blockIdx.x * 4 + 1] = t_epi; g.tim[blockIdx.x * 4 + 2] = t_first; g.tim[blockIdx.x * 4 + 3] = ((unsigned long long)(round + 1) << 40) | t_bar; }
 }
@@ -420,17 +454,17 @@ int launch_tail(hipStream_t s, const PArgs& g, int act) {
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
     static bool attr_set = false;
     if (!attr_set) {
-        bool ok = hipFuncSetAttribute((const void*)gemm_persist_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+        bool ok = hipFuncSetAttribute((const void*)gemm_persist_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
         if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
-    if (act == SETOK_ACT_NONE) gemm_persist_kernel<0><<<grid, 512, MAIN_LDS, s>>>(g);
-    else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1><<<grid, 512, MAIN_LDS, s>>>(g);
-    else gemm_persist_kernel<2><<<grid, 512, MAIN_LDS, s>>>(g);
+    if (act == SETOK_ACT_NONE) gemm_persist_kernel<0, false><<<grid, 512, MAIN_LDS, s>>>(g);
+    else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1, false><<<grid, 512, MAIN_LDS, s>>>(g);
+    else gemm_persist_kernel<2, false><<<grid, 512, MAIN_LDS, s>>>(g);
     SETOK_CHECK_LAUNCH("setok_linear(persistent)");
     return SETOK_OK;
 }
@@ -464,7 +498,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
-    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr};
+    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1};
     if (!bias) {
         static const float* zb = [] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(kZeroBias)) == hipSuccess ? (const float*)q : nullptr; }();
         if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
@@ -484,6 +518,26 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (rc != SETOK_OK || p == 0) return rc;
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
-            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr};
+            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1};
     return launch_tail(s, t, act);
+}
+
+// Called by setok_linear for bf16 -> fp32 batched problems (no bias / activation / residual): the split-K partial products of a weight
+// gradient.  Same kernel, F32B variant.
+int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
+                                   int64_t sA, int64_t sW, int64_t sC) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) != hipSuccess)
+            return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    static const float* zb = [] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(kZeroBias)) == hipSuccess ? (const float*)q : nullptr; }();
+    if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
+    const int tilesM = cdiv(M, TM), tilesN = cdiv(N, 256);
+    PArgs g{A, W, nullptr, nullptr, nullptr, lda, ldc, M, N, K, tilesM, tilesN, 0, nullptr, zb, C, sA, sW, sC, batch};
+    const int tiles = tilesM * tilesN * batch, ncu = cu_count();
+    gemm_persist_kernel<0, true><<<tiles < ncu ? tiles : ncu, 512, MAIN_LDS, s>>>(g);
+    SETOK_CHECK_LAUNCH("setok_linear(persistent, fp32 batched)");
+    return SETOK_OK;
 }
