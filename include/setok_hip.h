@@ -215,6 +215,30 @@ int setok_segment_mean_bwd(void* stream, int dtype, const void* dseg, const int3
 int setok_adamw(void* stream, int lp_dtype, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_lp,
                 int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
 
+/* ---- LLM prefill of BASELINE config 5 (last row) -------------------------------------------------------------
+ * SetokimLlamaForCausalLM.forward (src/model/language_model/setokim_llama.py:130-143) hands the spliced embeddings to
+ * `self.model` — HuggingFace `transformers` LlamaModel (third party, pinned 4.46.3 by the reference) — and `self.lm_head`.
+ * Its Linears are setok_linear calls; these are the other pieces of LlamaDecoderLayer.forward (eager path). */
+
+/* LlamaRMSNorm.forward: y = weight * (x * rsqrt(mean(x^2) + eps)).to(dtype) — statistics in fp32, the normalised value rounded
+ * to the activation dtype before the weight multiply. */
+int setok_rmsnorm(void* stream, int dtype, const void* x, const float* weight, void* y, int rows, int C, float eps);
+
+/* apply_rotary_pos_emb (rotate_half convention, default rope: inv_freq = theta^(-2i/Dh), cos / sin in fp32 rounded to dtype) in
+ * place on the q and k thirds of qkv: (rows, 3*H*Dh) laid out [q | k | v]; position_ids: int64[rows]. */
+int setok_rope(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Dh, float theta);
+
+/* LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) on a fused (rows, 2*F) buffer [gate | up] -> (rows, F); act_fn = SiLU. */
+int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_t rows, int F);
+
+/* Causal self-attention of LlamaAttention (eager_attention_forward: softmax(q k^T * scale + mask) v, fp32 softmax) over B
+ * sequences of T rows of a fused [q | k | v] buffer (num_key_value_heads == num_attention_heads).  Query i of a sequence sees key
+ * j iff j <= i and key_mask[b*T + j] != 0 (key_mask NULL = all tokens): the causal + padding mask HF builds from attention_mask.
+ * A query that sees no token at all (padding before a sequence's first token) gets zeros (HF gives such rows an arbitrary uniform
+ * mix; they are padding and masked out of the loss, setokim_llama.py:149-152). */
+int setok_attention_causal(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Dh,
+                           float scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -689,6 +689,121 @@ def splice_inputs(seed, B, T, V, D, max_imgs=3, pad=True):
 
 
 # ----------------------------------------------------------------------------------------------
+# §8(f) last row — the LLM prefill of cfg 5: SetokimLlamaForCausalLM.forward (setokim_llama.py:94-143) = the splice above, then
+# `self.model(inputs_embeds=..., attention_mask=..., position_ids=...)` and `self.lm_head` (:130-143).  `self.model` is HuggingFace
+# `transformers` LlamaModel (third party; reference pin transformers==4.46.3, pyproject.toml:18; 5.15.0 installed here — same
+# arithmetic on the eager attention path): restated here from its published algorithm and pinned against the installed implementation.
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class LlamaConfigLite:
+    """Subset of HF LlamaConfig the prefill arithmetic reads (defaults = Vicuna-7B v1.5 / Llama-2-7B)."""
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    vocab_size: int = 32000
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+def llama_rmsnorm(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    """LlamaRMSNorm.forward: statistics in fp32, the normalised value cast back to the input dtype BEFORE the weight multiply."""
+    h = x.float()
+    h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return w * h.to(x.dtype)
+
+
+def llama_rope_tables(position_ids: Tensor, head_dim: int, theta: float, dtype) -> Tuple[Tensor, Tensor]:
+    """LlamaRotaryEmbedding.forward (default rope): fp32 inv_freq x position, emb = cat(freqs, freqs), cos / sin cast to dtype."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    freqs = position_ids[:, :, None].float() * inv_freq[None, None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rotate_half(x: Tensor) -> Tensor:
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def llama_forward(sd: Dict[str, Tensor], lc: LlamaConfigLite, inputs_embeds: Tensor, attention_mask: Optional[Tensor],
+                  position_ids: Optional[Tensor] = None, with_logits: bool = True, prefix: str = "model."):
+    """LlamaModel.forward on inputs_embeds (B, T, D) (eager attention, no cache) + lm_head (setokim_llama.py:130-143).
+    attention_mask (B, T): 1 = token; the additive mask is causal AND key-padding (masked = dtype min, as HF builds it).
+    Returns (hidden_states after the final norm, logits or None)."""
+    B, T, D = inputs_embeds.shape
+    H, Hkv, dh = lc.num_attention_heads, lc.num_key_value_heads, lc.head_dim
+    if position_ids is None:
+        position_ids = torch.arange(T)[None].expand(B, T)
+    cos, sin = llama_rope_tables(position_ids, dh, lc.rope_theta, inputs_embeds.dtype)
+    cos, sin = cos[:, None], sin[:, None]
+    neg = torch.finfo(inputs_embeds.dtype).min
+    allow = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None]
+    if attention_mask is not None:
+        allow = allow & attention_mask.bool()[:, None, None, :]
+    add = torch.zeros((B, 1, T, T), dtype=inputs_embeds.dtype).masked_fill(~allow, neg)
+    x = inputs_embeds
+    for i in range(lc.num_hidden_layers):
+        p = prefix + f"layers.{i}."
+        y = llama_rmsnorm(x, sd[p + "input_layernorm.weight"], lc.rms_norm_eps)
+        q = F.linear(y, sd[p + "self_attn.q_proj.weight"]).view(B, T, H, dh).transpose(1, 2)
+        k = F.linear(y, sd[p + "self_attn.k_proj.weight"]).view(B, T, Hkv, dh).transpose(1, 2)
+        v = F.linear(y, sd[p + "self_attn.v_proj.weight"]).view(B, T, Hkv, dh).transpose(1, 2)
+        q = (q * cos) + (_rotate_half(q) * sin)
+        k = (k * cos) + (_rotate_half(k) * sin)
+        if Hkv != H:
+            k = k.repeat_interleave(H // Hkv, dim=1); v = v.repeat_interleave(H // Hkv, dim=1)
+        w = torch.matmul(q, k.transpose(2, 3)) * dh ** -0.5 + add
+        w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = torch.matmul(w, v).transpose(1, 2).reshape(B, T, D)
+        x = x + F.linear(o, sd[p + "self_attn.o_proj.weight"])
+        y = llama_rmsnorm(x, sd[p + "post_attention_layernorm.weight"], lc.rms_norm_eps)
+        g = F.silu(F.linear(y, sd[p + "mlp.gate_proj.weight"])) * F.linear(y, sd[p + "mlp.up_proj.weight"])
+        x = x + F.linear(g, sd[p + "mlp.down_proj.weight"])
+    hidden = llama_rmsnorm(x, sd[prefix + "norm.weight"], lc.rms_norm_eps)
+    logits = F.linear(hidden, sd["lm_head.weight"]) if with_logits else None
+    return hidden, logits
+
+
+def init_llama_weights(lc: LlamaConfigLite, seed: int = 7, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Seeded synthetic weights under HF LlamaForCausalLM's state-dict names (N(0, 0.02) Linears / embeddings as HF initialises,
+    RMSNorm weights near 1)."""
+    g = torch.Generator().manual_seed(seed)
+    D, Fd = lc.hidden_size, lc.intermediate_size
+    kv = lc.num_key_value_heads * lc.head_dim
+    sd = {"model.embed_tokens.weight": torch.randn(lc.vocab_size, D, generator=g) * 0.02,
+          "lm_head.weight": torch.randn(lc.vocab_size, D, generator=g) * 0.02,
+          "model.norm.weight": 1.0 + 0.05 * torch.randn(D, generator=g)}
+    for i in range(lc.num_hidden_layers):
+        p = f"model.layers.{i}."
+        sd[p + "input_layernorm.weight"] = 1.0 + 0.05 * torch.randn(D, generator=g)
+        sd[p + "post_attention_layernorm.weight"] = 1.0 + 0.05 * torch.randn(D, generator=g)
+        for n, (o, ii) in {"self_attn.q_proj": (D, D), "self_attn.k_proj": (kv, D), "self_attn.v_proj": (kv, D), "self_attn.o_proj": (D, D),
+                           "mlp.gate_proj": (Fd, D), "mlp.up_proj": (Fd, D), "mlp.down_proj": (D, Fd)}.items():
+            sd[p + n + ".weight"] = torch.randn(o, ii, generator=g) * 0.02 * (2.0 if "proj" in n else 1.0)
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
+def llama_inputs(lc, seed, B, T, padding):
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(B, T, lc.hidden_size, generator=g)
+    am = torch.ones(B, T, dtype=torch.long)
+    for b in range(1, B):
+        n = int(torch.randint(T // 3, T, (1,), generator=g))
+        if padding == "right":
+            am[b, n:] = 0
+        else:
+            am[b, :T - n] = 0
+    pos = (am.cumsum(-1) - 1).clamp_min(0) if padding == "left" else torch.arange(T)[None].expand(B, T).clone()
+    return x, am, pos
+
+
+# ----------------------------------------------------------------------------------------------
 # seeded synthetic weights (no pretrained weights / network exist: SURVEY.md §8d)
 # ----------------------------------------------------------------------------------------------
 def init_head_weights(hc: HeadConfig, seed: int = 1, dtype=torch.float32) -> Dict[str, Tensor]:

@@ -41,6 +41,10 @@ SIGNATURES = {
     "setok_attention_bwd": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "setok_segment_mean_bwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i],
     "setok_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f],
+    "setok_rmsnorm": [_vp, _i, _vp, _vp, _vp, _i, _i, _f],
+    "setok_rope": [_vp, _i, _vp, _vp, _i, _i, _i, _f],
+    "setok_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
+    "setok_attention_causal": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f],
     "setok_splice_rows": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _i],
 }
 

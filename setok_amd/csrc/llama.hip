@@ -1,0 +1,303 @@
+// llama.hip — what the LLM prefill of BASELINE config 5 needs beyond setok_linear: the pieces of HuggingFace LlamaModel.forward that
+// SetokimLlamaForCausalLM.forward (src/model/language_model/setokim_llama.py:130-139) runs on the spliced embeddings.
+//   setok_rmsnorm           LlamaRMSNorm (fp32 statistics, normalised value rounded to the activation dtype BEFORE the weight multiply)
+//   setok_rope              apply_rotary_pos_emb on the q and k thirds of a fused [q | k | v] buffer (rotate_half convention, cos / sin in fp32
+//                           rounded to the activation dtype, every elementwise product / sum rounded like the eager bf16 graph)
+//   setok_swiglu            act_fn(gate) * up on a fused [gate | up] buffer
+//   setok_attention_causal  causal + key-padding-masked attention over uniform sequences: MFMA kernel for bf16 / head dim 128 (keys and
+//                           values streamed through LDS in tiles of 32, online softmax in registers), generic wave-per-row kernel otherwise
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ inline float rnd(float v) { return (float)(T)v; }      // one rounding to the activation dtype
+
+// ---- RMSNorm ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int rows, int C,
+                                                      float eps) {
+    constexpr int V = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (int64_t)row * C;
+    float buf[V], s = 0.f;
+    for (int c = lane * V; c < C; c += 64 * V) {
+        ld_vec<T>(xr + c, buf);
+#pragma unroll
+        for (int i = 0; i < V; ++i) s += buf[i] * buf[i];
+    }
+    const float rstd = rsqrtf(wave_sum(s) / (float)C + eps);
+    for (int c = lane * V; c < C; c += 64 * V) {
+        ld_vec<T>(xr + c, buf);
+#pragma unroll
+        for (int i = 0; i < V; ++i) buf[i] = rnd<T>(w[c + i]) * rnd<T>(buf[i] * rstd);   // weight * hidden.to(input_dtype)
+        st_vec<T>(y + (int64_t)row * C + c, buf);
+    }
+}
+
+// ---- rotary embedding on q and k of [q | k | v] rows -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Dh, float log2_theta) {
+    const int half = Dh >> 1;
+    const int64_t total = (int64_t)rows * 2 * H * half;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % half);
+        const int hh = (int)((i / half) % (2 * H));                      // head index over q then k
+        const int64_t r = i / ((int64_t)half * 2 * H);
+        const float inv_freq = 1.0f / exp2f(log2_theta * (float)(2 * d) / (float)Dh);
+        const float ang = (float)pos[r] * inv_freq;
+        const float c = rnd<T>(cosf(ang)), s = rnd<T>(sinf(ang));
+        T* p = qkv + r * (int64_t)(3 * H * Dh) + (int64_t)hh * Dh + d;
+        const float x1 = (float)p[0], x2 = (float)p[half];
+        p[0] = (T)(rnd<T>(x1 * c) + rnd<T>(-x2 * s));                     // q * cos + rotate_half(q) * sin, each op rounded
+        p[half] = (T)(rnd<T>(x2 * c) + rnd<T>(x1 * s));
+    }
+}
+
+// ---- SwiGLU ------------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int64_t rows, int F) {
+    const int64_t total = rows * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / F; const int c = (int)(i % F);
+        const float g = (float)gu[r * 2 * F + c], u = (float)gu[r * 2 * F + F + c];
+        out[i] = (T)(rnd<T>(g / (1.0f + expf(-g))) * u);
+    }
+}
+
+// ---- generic causal attention: one wave per (query row, head) ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void attn_causal_generic_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ kmask, T* __restrict__ out,
+                                                                 int Tn, int H, int Dh, float scale) {
+    extern __shared__ float ps[];                                      // Tn scores
+    const int row = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int b = row / Tn, i = row % Tn;
+    const int64_t C = (int64_t)H * Dh, ld = 3 * C;
+    const T* base = qkv + (int64_t)b * Tn * ld + h * Dh;
+    float mx = -INFINITY;
+    for (int j = lane; j <= i; j += 64) {
+        float acc = -INFINITY;
+        if (!kmask || kmask[(int64_t)b * Tn + j]) {
+            acc = 0.f;
+            for (int d = 0; d < Dh; ++d) acc = fmaf((float)base[(int64_t)i * ld + d], (float)base[(int64_t)j * ld + C + d], acc);
+            acc *= scale;
+        }
+        ps[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= i; j += 64) { const float e = mx == -INFINITY ? 0.f : expf(ps[j] - mx); ps[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    for (int d = lane; d < Dh; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j <= i; ++j) o = fmaf(rnd<T>(ps[j] * inv), (float)base[(int64_t)j * ld + 2 * C + d], o);   // probabilities cast to dtype (HF)
+        out[((int64_t)b * Tn + i) * C + h * Dh + d] = (T)o;
+    }
+}
+
+// ---- bf16 MFMA causal attention, head dim 128 --------------------------------------------------------------------------------------------------
+constexpr int CD = 128;                  // head dim
+constexpr int CROW = CD * 2;             // bytes per K / V row in LDS
+constexpr int CQ = 128;                  // queries per workgroup (4 waves x 32)
+typedef __attribute__((ext_vector_type(4))) short short4v;
+
+__device__ inline bf16x8 pack8c(const float* p) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)p[i];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attn_causal_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask, bf16* __restrict__ out,
+                                                          int Tn, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char Ks[2][32 * CROW];       // K tile, 16-byte slots XOR-swizzled by (row & 15)
+    __shared__ __attribute__((aligned(16))) char Vs[2][32 * CROW];       // V tile, row-major (hardware-transposing reads)
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;                 // heavy (late) query blocks first: the causal triangle
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, hi = lane >> 5;
+    const int64_t C = (int64_t)H * CD, ld = 3 * C;
+    const bf16* base = qkv + (int64_t)b * Tn * ld + h * CD;
+    const uint8_t* km = kmask ? kmask + (int64_t)b * Tn : nullptr;
+    const int q0 = qb * CQ + wave * 32;                                  // this wave's first query
+    const int q = q0 + qi;
+    const bf16* qp = base + (int64_t)min(q, Tn - 1) * ld + hi * 8;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    constexpr float NEG = -1.0e30f;                                      // finite sentinel: a query may meet only masked keys first (left padding)
+    float m_run = NEG, l_run = 0.f;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int tr_row = (i16 >> 2) + 4 * (g16 >> 1);
+    const int tr_col = (g16 & 1) * 16 + (i16 & 3) * 4;
+    const unsigned klds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)&Ks[0][0]) + wave * 1024;
+    const unsigned vlds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)&Vs[0][0]) + wave * 1024;
+    const int kend = min(qb * CQ + CQ, Tn);                              // keys this block can see: [0, kend)
+    const int nkt = (kend + 31) >> 5;
+    auto stage = [&](int kt, int buf) {                                  // K and V tile kt -> LDS buffer buf: 512 pieces of 16 B each, 2 per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = i * 256 + tid, row = p >> 4, c = p & 15;
+            const bf16* src = base + (int64_t)min(kt * 32 + row, Tn - 1) * ld;
+            const bf16* ksrc = src + C + ((c ^ (row & 15)) << 3);        // physical slot c of a row holds logical chunk c ^ (row & 15)
+            const bf16* vsrc = src + 2 * C + (c << 3);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(ksrc), "s"(klds + buf * (32 * CROW) + i * 4096) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(vsrc), "s"(vlds + buf * (32 * CROW) + i * 4096) : "memory");
+        }
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this thread's pieces of tile kt
+        __syncthreads();                                                 // everyone's; everyone is done with the other buffer
+        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+        const int k0 = kt * 32;
+        if (k0 > q0 + 31) continue;                                      // wave-uniform: the whole tile lies in this wave's future
+        // key-padding mask of the tile as a 32-bit set (bit j = key k0 + j is a token)
+        unsigned kbits = 0xffffffffu;
+        if (km) kbits = (unsigned)__ballot(lane < 32 && k0 + lane < Tn && km[min(k0 + lane, Tn - 1)] != 0);
+        else if (k0 + 32 > Tn) kbits = (unsigned)__ballot(lane < 32 && k0 + lane < Tn);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* Kb = &Ks[buf][0];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kb + qi * CROW + (((ks * 2 + hi) ^ (qi & 15)) << 4));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        float t[16];
+        float mx = NEG;
+        const bool diag = k0 + 31 > q0;                                  // some key of the tile may lie after some query of the wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = (r & 3) + 8 * (r >> 2) + 4 * hi;              // key index inside the tile
+            t[r] = s[r];
+            if (!((kbits >> kj) & 1u) || (diag && k0 + kj > q)) t[r] = NEG;
+            mx = fmaxf(mx, t[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * scale_log2e;
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { t[r] = t[r] <= NEG ? 0.f : __builtin_amdgcn_exp2f(fmaf(t[r], scale_log2e, -mc)); ls += t[r]; }
+        l_run += ls;
+        const bf16x8 p0 = pack8c(t), p1 = pack8c(t + 8);
+        const char* Vb = &Vs[buf][0];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const char* va = Vb + (k2 * 16 + tr_row) * CROW + (d * 32 + tr_col) * 2;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(va));
+                const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(va + 8 * CROW));
+                union { short s8[8]; bf16x8 v; } u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { u.s8[j] = lo[j]; u.s8[4 + j] = hi4[j]; }
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, k2 == 0 ? p0 : p1, o[d], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;                  // a query without any visible token (padding before the first token): zeros
+    if (q < Tn) {
+        bf16* op = out + ((int64_t)b * Tn + q) * C + h * CD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[d][r4 * 4 + j] * inv);
+                *reinterpret_cast<bf16x4*>(op + d * 32 + 8 * r4 + 4 * hi) = v;
+            }
+    }
+}
+
+}  // namespace
+
+#define LL_DISPATCH(NAME, CALL_BF16, CALL_F32)                                 \
+    if (dtype == SETOK_BF16) { CALL_BF16; }                                    \
+    else if (dtype == SETOK_F32) { CALL_F32; }                                 \
+    else return setok_fail(SETOK_EINVAL, NAME ": bad dtype %d", dtype);
+
+extern "C" int setok_rmsnorm(void* stream, int dtype, const void* x, const float* weight, void* y, int rows, int C, float eps) {
+    SETOK_CHECK_ARG(x && weight && y, "setok_rmsnorm: null operand");
+    SETOK_CHECK_ARG(rows >= 0 && C > 0 && C % 8 == 0, "setok_rmsnorm: C=%d must be a positive multiple of 8", C);
+    if (rows == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    LL_DISPATCH("setok_rmsnorm", (rmsnorm_kernel<bf16><<<cdiv(rows, 4), 256, 0, s>>>((const bf16*)x, weight, (bf16*)y, rows, C, eps)),
+                (rmsnorm_kernel<float><<<cdiv(rows, 4), 256, 0, s>>>((const float*)x, weight, (float*)y, rows, C, eps)));
+    SETOK_CHECK_LAUNCH("setok_rmsnorm");
+    return SETOK_OK;
+}
+
+extern "C" int setok_rope(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Dh, float theta) {
+    SETOK_CHECK_ARG(qkv && position_ids, "setok_rope: null operand");
+    SETOK_CHECK_ARG(rows >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0 && theta > 0.f, "setok_rope: bad shape");
+    if (rows == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)rows * H * Dh;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    const float l2 = log2f(theta);
+    LL_DISPATCH("setok_rope", (rope_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Dh, l2)),
+                (rope_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Dh, l2)));
+    SETOK_CHECK_LAUNCH("setok_rope");
+    return SETOK_OK;
+}
+
+extern "C" int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_t rows, int F) {
+    SETOK_CHECK_ARG(gate_up && out && rows >= 0 && F > 0, "setok_swiglu: bad operand");
+    if (rows == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = rows * F;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    LL_DISPATCH("setok_swiglu", (swiglu_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)gate_up, (bf16*)out, rows, F)),
+                (swiglu_kernel<float><<<grid, 256, 0, s>>>((const float*)gate_up, (float*)out, rows, F)));
+    SETOK_CHECK_LAUNCH("setok_swiglu");
+    return SETOK_OK;
+}
+
+extern "C" int setok_attention_causal(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Dh,
+                                      float scale) {
+    SETOK_CHECK_ARG(qkv && out, "setok_attention_causal: null operand");
+    SETOK_CHECK_ARG(B >= 0 && T > 0 && H > 0 && Dh > 0 && Dh % 8 == 0, "setok_attention_causal: bad shape B=%d T=%d H=%d Dh=%d", B, T, H, Dh);
+    if (B == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16 && Dh == CD) {
+        attn_causal_kernel<<<dim3(cdiv(T, CQ), H, B), 256, 0, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, scale * 1.44269504088896340736f);
+        SETOK_CHECK_LAUNCH("setok_attention_causal(bf16 mfma)");
+        return SETOK_OK;
+    }
+    const size_t smem = (size_t)T * sizeof(float);
+    SETOK_CHECK_ARG(smem <= 64 * 1024, "setok_attention_causal: T=%d too long for the generic kernel", T);
+    dim3 grid(B * T, H);
+    LL_DISPATCH("setok_attention_causal",
+                (attn_causal_generic_kernel<bf16><<<grid, 64, smem, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, Dh, scale)),
+                (attn_causal_generic_kernel<float><<<grid, 64, smem, s>>>((const float*)qkv, key_mask, (float*)out, T, H, Dh, scale)));
+    SETOK_CHECK_LAUNCH("setok_attention_causal");
+    return SETOK_OK;
+}

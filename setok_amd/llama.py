@@ -1,0 +1,165 @@
+"""LLM prefill of BASELINE config 5 on the HIP library: what `SetokimLlamaForCausalLM.forward`
+(src/model/language_model/setokim_llama.py:94-143) runs after `prepare_inputs_labels_for_multimodal` —
+
+    outputs = self.model(attention_mask=..., position_ids=..., inputs_embeds=...)      # HF LlamaModel      :130-139
+    logits  = self.lm_head(outputs[0])                                                 #                    :143
+
+`self.model` is HuggingFace `transformers` LlamaModel (third-party code; Vicuna-7B = 32 layers, hidden 4096, 32 heads of 128, SwiGLU
+11008, RMSNorm, rotary embeddings).  This module holds the same parameters under the same state-dict names
+(`model.embed_tokens.weight`, `model.layers.{i}.self_attn.{q,k,v,o}_proj.weight`, `model.layers.{i}.mlp.{gate,up,down}_proj.weight`,
+`model.layers.{i}.{input,post_attention}_layernorm.weight`, `model.norm.weight`, `lm_head.weight`) so a Vicuna / Llama-2 checkpoint loads
+unchanged, and runs the prefill (no KV cache, eager-attention arithmetic) as: RMSNorm -> one fused q|k|v GEMM -> rotary embedding in place
+-> causal + padding-masked MFMA attention -> o_proj GEMM with the residual fused -> RMSNorm -> one fused gate|up GEMM -> SwiGLU ->
+down_proj GEMM with the residual fused.  Inference only; grouped-query attention (num_key_value_heads < num_attention_heads) is not
+implemented on the HIP path (Vicuna-7B / 13B do not use it).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .arch import SetokimVisionMixin
+
+
+class _RMSNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.variance_epsilon = eps
+
+
+class _Attention(nn.Module):
+    def __init__(self, D, H, Hkv):
+        super().__init__()
+        dh = D // H
+        self.q_proj = nn.Linear(D, H * dh, bias=False)
+        self.k_proj = nn.Linear(D, Hkv * dh, bias=False)
+        self.v_proj = nn.Linear(D, Hkv * dh, bias=False)
+        self.o_proj = nn.Linear(H * dh, D, bias=False)
+
+
+class _MLP(nn.Module):
+    def __init__(self, D, F):
+        super().__init__()
+        self.gate_proj = nn.Linear(D, F, bias=False)
+        self.up_proj = nn.Linear(D, F, bias=False)
+        self.down_proj = nn.Linear(F, D, bias=False)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, D, H, Hkv, F, eps):
+        super().__init__()
+        self.self_attn = _Attention(D, H, Hkv)
+        self.mlp = _MLP(D, F)
+        self.input_layernorm = _RMSNorm(D, eps)
+        self.post_attention_layernorm = _RMSNorm(D, eps)
+
+
+class LlamaModel(nn.Module):
+    """Parameter container with HF LlamaModel's tree + the prefill on the HIP library."""
+
+    def __init__(self, vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, num_key_value_heads, rms_norm_eps,
+                 rope_theta):
+        super().__init__()
+        if num_key_value_heads != num_attention_heads:
+            raise NotImplementedError("grouped-query attention is not implemented on the HIP path (Vicuna-7B/13B use plain multi-head attention)")
+        self.num_heads, self.head_dim, self.rope_theta, self.eps = num_attention_heads, hidden_size // num_attention_heads, rope_theta, rms_norm_eps
+        self.embed_tokens = nn.Embedding(vocab_size, hidden_size)
+        self.layers = nn.ModuleList([_DecoderLayer(hidden_size, num_attention_heads, num_key_value_heads, intermediate_size, rms_norm_eps)
+                                     for _ in range(num_hidden_layers)])
+        self.norm = _RMSNorm(hidden_size, rms_norm_eps)
+        self._packed: Dict[str, Any] = {}
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def _pack(self):
+        w = self.norm.weight
+        key = (w.dtype, str(w.device), w._version)
+        if self._packed.get("key") == key:
+            return self._packed
+        f32 = lambda t: t.detach().float().contiguous()
+        layers = []
+        for l in self.layers:
+            a, m = l.self_attn, l.mlp
+            layers.append(dict(n1=f32(l.input_layernorm.weight), n2=f32(l.post_attention_layernorm.weight),
+                               wqkv=torch.cat([a.q_proj.weight.detach(), a.k_proj.weight.detach(), a.v_proj.weight.detach()], 0).contiguous(),
+                               wo=a.o_proj.weight.detach().contiguous(),
+                               wgu=torch.cat([m.gate_proj.weight.detach(), m.up_proj.weight.detach()], 0).contiguous(),
+                               wd=m.down_proj.weight.detach().contiguous()))
+        self._packed = dict(key=key, layers=layers, norm=f32(self.norm.weight))
+        return self._packed
+
+    @torch.no_grad()
+    def forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None):
+        """inputs_embeds (B, T, D); attention_mask (B, T), 1 = token (None = all); position_ids (B, T) (None = 0..T-1).
+        Returns the hidden states after the final norm, (B, T, D)."""
+        B, T, D = inputs_embeds.shape
+        pk = self._pack()
+        H, dh = self.num_heads, self.head_dim
+        dev = inputs_embeds.device
+        x = inputs_embeds.to(self.norm.weight.dtype).reshape(B * T, D).contiguous().clone()
+        if position_ids is None:
+            position_ids = torch.arange(T, device=dev)[None].expand(B, T)
+        pos = position_ids.to(device=dev, dtype=torch.int64).reshape(B * T).contiguous()
+        km = None if attention_mask is None else attention_mask.to(device=dev).bool().to(torch.uint8).reshape(B * T).contiguous()
+        y = None
+        for L in pk["layers"]:
+            y = ops.rmsnorm(x, L["n1"], self.eps, out=y)
+            qkv = ops.linear(y, L["wqkv"])
+            ops.rope_(qkv, pos, H, dh, self.rope_theta)
+            o = ops.attention_causal(qkv, km, B, T, H, dh, dh ** -0.5)
+            ops.linear(o, L["wo"], residual=x, out=x)
+            y = ops.rmsnorm(x, L["n2"], self.eps, out=y)
+            gu = ops.linear(y, L["wgu"])
+            g = ops.swiglu(gu)
+            ops.linear(g, L["wd"], residual=x, out=x)
+        return ops.rmsnorm(x, pk["norm"], self.eps, out=y).reshape(B, T, D)
+
+
+class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
+    """`SetokimLlamaForCausalLM.forward` without the loss (setokim_llama.py:94-143): splice the image tokens into the text embeddings,
+    run the LLM over them, project to the vocabulary.  `vision_tower` / `mm_in_projector` are the SetokTokenizer and projector of the
+    encode path (may be None when `inputs_embeds` are passed directly)."""
+
+    def __init__(self, config: Any, vision_tower=None, mm_in_projector=None):
+        super().__init__()
+        g = (lambda k, d=None: config.get(k, d)) if isinstance(config, dict) else (lambda k, d=None: getattr(config, k, d))
+        self.config = config
+        self.model = LlamaModel(g("vocab_size"), g("hidden_size"), g("intermediate_size"), g("num_hidden_layers"), g("num_attention_heads"),
+                                g("num_key_value_heads", g("num_attention_heads")), g("rms_norm_eps", 1e-5), g("rope_theta", 10000.0))
+        self.lm_head = nn.Linear(g("hidden_size"), g("vocab_size"), bias=False)
+        self.vision_tower = vision_tower
+        self.mm_in_projector = mm_in_projector
+
+    def get_model(self):
+        return self.model
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, labels=None, comp_images=None,
+                last_token_only: bool = False):
+        """Returns (logits, new_labels, attention_mask): logits (B, T', vocab) — or (B, vocab) for every sequence's last token with
+        `last_token_only` (what a generation step after the prefill needs) — on the spliced sequence of length T'."""
+        new_labels = labels
+        if inputs_embeds is None:
+            _, position_ids, attention_mask, _, inputs_embeds, new_labels = self.prepare_inputs_labels_for_multimodal(
+                input_ids, position_ids, attention_mask, None, labels, comp_images)
+            if inputs_embeds is None:                                              # no images: plain text
+                inputs_embeds = self.model.embed_tokens(input_ids)
+        hidden = self.model(inputs_embeds, attention_mask, position_ids)           # setokim_llama.py:130-140
+        B, T, D = hidden.shape
+        w = self.lm_head.weight.detach().contiguous()
+        if last_token_only:
+            if attention_mask is None:
+                last = torch.full((B,), T - 1, device=hidden.device)
+            else:
+                am = attention_mask.to(hidden.device).bool()
+                last = (am * torch.arange(T, device=hidden.device)[None]).max(dim=1).values
+            rows = hidden[torch.arange(B, device=hidden.device), last].contiguous()
+            return ops.linear(rows, w), new_labels, attention_mask
+        logits = ops.linear(hidden.reshape(B * T, D), w).reshape(B, T, -1)         # :143
+        return logits, new_labels, attention_mask

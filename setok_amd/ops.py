@@ -362,3 +362,37 @@ def adamw(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, para
     lp = _code(param_lp.dtype) if param_lp is not None else 0
     _lib.call("setok_adamw", _stream(), lp, _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param_lp), n, lr, beta1, beta2, eps,
               weight_decay, step, grad_scale)
+
+
+# ---- LLM prefill (csrc/llama.hip) ------------------------------------------------------------------------------------------------
+def rmsnorm(x: Tensor, weight: Tensor, eps: float, out: Optional[Tensor] = None) -> Tensor:
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    w = weight if weight.dtype == torch.float32 else weight.float()       # a bf16 weight is exact in fp32; the kernel re-rounds it to the activation dtype
+    _lib.call("setok_rmsnorm", _stream(), _code(x.dtype), _p(x), _p(w.contiguous()), _p(out), rows, Cc, eps)
+    return out
+
+
+def rope_(qkv: Tensor, position_ids: Tensor, H: int, Dh: int, theta: float) -> Tensor:
+    """In place on the q and k thirds of qkv (rows, 3*H*Dh)."""
+    rows = qkv.shape[0]
+    assert qkv.shape[1] == 3 * H * Dh and position_ids.dtype == torch.int64 and position_ids.numel() == rows
+    _lib.call("setok_rope", _stream(), _code(qkv.dtype), _p(qkv), _p(position_ids.contiguous()), rows, H, Dh, theta)
+    return qkv
+
+
+def swiglu(gate_up: Tensor) -> Tensor:
+    rows, F2 = gate_up.shape
+    out = torch.empty((rows, F2 // 2), dtype=gate_up.dtype, device=gate_up.device)
+    _lib.call("setok_swiglu", _stream(), _code(gate_up.dtype), _p(gate_up), _p(out), rows, F2 // 2)
+    return out
+
+
+def attention_causal(qkv: Tensor, key_mask: Optional[Tensor], B: int, T: int, H: int, Dh: int, scale: float) -> Tensor:
+    assert qkv.shape == (B * T, 3 * H * Dh)
+    if key_mask is not None:
+        assert key_mask.dtype == torch.uint8 and key_mask.numel() == B * T
+    out = torch.empty((B * T, H * Dh), dtype=qkv.dtype, device=qkv.device)
+    _lib.call("setok_attention_causal", _stream(), _code(qkv.dtype), _p(qkv), _p(key_mask), _p(out), B, T, H, Dh, scale)
+    return out

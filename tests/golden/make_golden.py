@@ -284,14 +284,49 @@ def gen_head_grads():
     save("head_grads", **arrs)
 
 
+# ----------------------------------------------------------------------------------------------
+LLAMA_CASES = {
+    # name: (LlamaConfigLite kwargs, seed, B, T, padding)
+    "tiny_right": (dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100), 7, 3, 11, "right"),
+    "tiny_left": (dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100), 8, 3, 11, "left"),
+    "dh128": (dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=128), 9, 2, 150, "right"),
+    "dh128_left": (dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=128), 10, 2, 70, "left"),
+}
+
+
+def gen_llama():
+    """cfg 5 (SURVEY.md 8f last row): HuggingFace LlamaForCausalLM (the `self.model` / `self.lm_head` of setokim_llama.py:130-143; third
+    party, installed transformers, eager attention, fp32) on seeded inputs_embeds / attention_mask / position_ids.  Weights regenerate from
+    the seed (oracle.init_llama_weights); stored: the HF logits and final hidden states."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    arrs = {}
+    for name, (kw, seed, B, T, padding) in LLAMA_CASES.items():
+        lc = O.LlamaConfigLite(**kw)
+        sd = O.init_llama_weights(lc, seed=seed)
+        cfg = LlamaConfig(**kw, rms_norm_eps=lc.rms_norm_eps, rope_theta=lc.rope_theta, attention_bias=False, mlp_bias=False, tie_word_embeddings=False)
+        cfg._attn_implementation = "eager"
+        m = LlamaForCausalLM(cfg).eval()
+        m.load_state_dict(sd, strict=True)
+        x, am, pos = O.llama_inputs(lc, seed, B, T, padding)
+        with torch.no_grad():
+            out = m(inputs_embeds=x, attention_mask=am, position_ids=pos, output_hidden_states=True)
+        arrs[name + ":cfg_keys"] = np.array(list(kw.keys())); arrs[name + ":cfg_vals"] = np.array(list(kw.values()))
+        arrs[name + ":spec"] = np.array([seed, B, T, 1 if padding == "left" else 0])
+        arrs[name + ":logits"] = npy(out.logits); arrs[name + ":hidden"] = npy(out.hidden_states[-1])
+        print(name, "HF logits", tuple(out.logits.shape))
+    save("llama", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads"]
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads", "llama"]
     if "detok" in which:
         gen_detok()
     if "splice" in which:
         gen_splice()
     if "head_grads" in which:
         gen_head_grads()
+    if "llama" in which:
+        gen_llama()
     if "head_small" in which:
         gen_head_small()
     if "cluster_full" in which:

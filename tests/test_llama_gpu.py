@@ -1,0 +1,145 @@
+"""cfg 5 on a real MI355X: the LLM prefill (setok_amd.llama, csrc/llama.hip + setok_linear) through the C ABI against HuggingFace
+LlamaForCausalLM's outputs (tests/golden/llama.npz) and torch references of each new op.  `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import setok_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import setok_amd
+    from setok_amd import ops
+    from setok_amd.llama import SetokimLlamaPrefill
+
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _rand(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+def test_rmsnorm(dt, tol):
+    x, w = (_rand(37, 256, seed=1) * 3).to(dt), (1 + 0.1 * _rand(256, seed=2)).to(dt)
+    ref = O.llama_rmsnorm(x.float().to(dt), w, 1e-5)
+    got = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5)
+    assert _rel(got, ref.double()) < tol
+    if dt == torch.bfloat16:                              # same two roundings as the eager bf16 graph: at most 1 bf16 ulp apart
+        assert float((got.cpu().float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_rope(dt, tol):
+    rows, H, Dh = 50, 3, 32
+    qkv = _rand(rows, 3 * H * Dh, seed=3).to(dt)
+    pos = torch.randint(0, 3000, (rows,), generator=torch.Generator().manual_seed(4))
+    cos, sin = O.llama_rope_tables(pos[None], Dh, 10000.0, dt)
+    q = qkv[:, :2 * H * Dh].reshape(rows, 2 * H, Dh)
+    ref = (q * cos[0][:, None]) + (O._rotate_half(q) * sin[0][:, None])
+    got = ops.rope_(qkv.to(DEV).clone(), pos.to(DEV), H, Dh, 10000.0).cpu()
+    assert _rel(got[:, :2 * H * Dh], ref.reshape(rows, -1).double()) < tol
+    assert torch.equal(got[:, 2 * H * Dh:], qkv[:, 2 * H * Dh:])            # v untouched
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+def test_swiglu(dt, tol):
+    gu = (_rand(33, 2 * 176, seed=5) * 2).to(dt)
+    ref = F.silu(gu[:, :176]) * gu[:, 176:]
+    assert _rel(ops.swiglu(gu.to(DEV)), ref.double()) < tol
+
+
+def _causal_ref(qkv, km, B, T, H, Dh):
+    q, k, v = [t.reshape(B, T, H, Dh).transpose(1, 2).double() for t in qkv.double().reshape(B, T, 3, H * Dh).unbind(2)]
+    allow = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None] & km.bool().reshape(B, 1, 1, T)
+    s = (q @ k.transpose(-1, -2)) * Dh ** -0.5
+    s = s.masked_fill(~allow, float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    return (p @ v).transpose(1, 2).reshape(B * T, H * Dh)
+
+
+@pytest.mark.parametrize("dt,tol,H,Dh,T", [(torch.float32, 3e-6, 3, 16, 37), (torch.bfloat16, 1e-2, 2, 128, 300), (torch.bfloat16, 1e-2, 3, 128, 129),
+                                            (torch.bfloat16, 1e-2, 1, 128, 31), (torch.bfloat16, 2e-2, 2, 64, 70)])
+def test_attention_causal_with_padding(dt, tol, H, Dh, T):
+    B = 3
+    qkv = _rand(B * T, 3 * H * Dh, seed=6).to(dt)
+    km = torch.ones(B, T, dtype=torch.uint8)
+    km[1, T - T // 3:] = 0                                 # right padding
+    km[2, :T // 4] = 0                                     # left padding: the first queries see no token at all -> zeros
+    ref = _causal_ref(qkv, km, B, T, H, Dh)
+    got = ops.attention_causal(qkv.to(DEV), km.reshape(-1).to(DEV), B, T, H, Dh, Dh ** -0.5)
+    assert _rel(got, ref) < tol
+    assert float(got.reshape(B, T, -1)[2, :T // 4].abs().max()) == 0.0
+    nomask = ops.attention_causal(qkv.to(DEV), None, B, T, H, Dh, Dh ** -0.5)
+    assert _rel(nomask, _causal_ref(qkv, torch.ones(B, T), B, T, H, Dh)) < tol
+
+
+def _case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "llama.npz"))
+    kw = {str(k): int(v) for k, v in zip(z[name + ":cfg_keys"], z[name + ":cfg_vals"])}
+    lc = O.LlamaConfigLite(**kw)
+    seed, B, T, left = [int(v) for v in z[name + ":spec"]]
+    sd = O.init_llama_weights(lc, seed=seed)
+    x, am, pos = O.llama_inputs(lc, seed, B, T, "left" if left else "right")
+    return kw, sd, x, am, pos, _t(z[name + ":hidden"]), _t(z[name + ":logits"])
+
+
+@pytest.mark.parametrize("name", ["tiny_right", "tiny_left", "dh128", "dh128_left"])
+def test_llama_prefill_fp32_vs_hf(golden_dir, name):
+    kw, sd, x, am, pos, hidden, logits = _case(golden_dir, name)
+    m = SetokimLlamaPrefill(kw)
+    assert not m.load_state_dict(sd, strict=True).missing_keys          # HF LlamaForCausalLM's key names
+    m = m.to(DEV).eval()
+    lg, _, _ = m(inputs_embeds=x.to(DEV), attention_mask=am.to(DEV), position_ids=pos.to(DEV))
+    v = am.bool()
+    assert _rel(lg.cpu()[v], logits[v]) < 1e-4
+    last, _, _ = m(inputs_embeds=x.to(DEV), attention_mask=am.to(DEV), position_ids=pos.to(DEV), last_token_only=True)
+    idx = (am * torch.arange(am.shape[1])[None]).max(1).values
+    assert _rel(last.cpu(), logits[torch.arange(am.shape[0]), idx]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["dh128", "dh128_left"])
+def test_llama_prefill_bf16_mfma_attention(golden_dir, name):
+    kw, sd, x, am, pos, hidden, logits = _case(golden_dir, name)
+    m = SetokimLlamaPrefill(kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device=DEV, dtype=torch.bfloat16).eval()
+    lg, _, _ = m(inputs_embeds=x.to(DEV), attention_mask=am.to(DEV), position_ids=pos.to(DEV))
+    v = am.bool()
+    assert lg.dtype == torch.bfloat16 and _rel(lg.float().cpu()[v], logits[v]) < 4e-2      # bf16 throughput mode: documented tolerance
+    one, _, _ = m(inputs_embeds=x[1:2].to(DEV), attention_mask=am[1:2].to(DEV), position_ids=pos[1:2].to(DEV))
+    assert torch.equal(one[0][am[1].bool().to(DEV)], lg[1][am[1].bool().to(DEV)])        # a sequence alone == inside the batch, bit-exact
+
+
+def test_setokim_forward_splices_then_prefills():
+    """input_ids with image placeholders + images -> splice -> LLM -> logits, against the oracle's splice + llama_forward (fp32)."""
+    kw = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100)
+    lc = O.LlamaConfigLite(**kw)
+    sd = O.init_llama_weights(lc, seed=11)
+    ids, am, labels, feats, _ = O.splice_inputs(12, 4, 10, 100, 64)
+
+    class Tower:
+        pass
+
+    m = SetokimLlamaPrefill(kw, vision_tower=Tower())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.encode_images = lambda images, **k: [f.to(DEV) for f in feats]
+    lg, new_labels, new_am = m(input_ids=ids.to(DEV), attention_mask=am.to(DEV), labels=labels.to(DEV), comp_images=torch.zeros(len(feats), 3, 2, 2))
+    _, ram, remb, rlab = O.splice_multimodal(ids, None, am, labels, feats, sd["model.embed_tokens.weight"])
+    _, ref = O.llama_forward(sd, lc, remb, ram, None)
+    assert torch.equal(new_am.cpu(), ram) and torch.equal(new_labels.cpu(), rlab)
+    assert _rel(lg.cpu()[ram.bool()], ref[ram.bool()]) < 1e-4

@@ -263,3 +263,28 @@ def test_head_param_grads_match_reference_autograd(golden_dir):
     assert set(names) == set(grads) and len(names) == 34
     for n in names:
         torch.testing.assert_close(grads[n], _t(gz["g:" + n]), rtol=1e-5, atol=1e-6)
+
+
+# ---- §8(f) last row: the LLM prefill of cfg 5 -------------------------------------------------------------------------------
+LLAMA_NAMES = ["tiny_right", "tiny_left", "dh128", "dh128_left"]
+
+
+def _llama_case(golden_dir, name):
+    z = _load(golden_dir, "llama")
+    kw = {str(k): int(v) for k, v in zip(z[name + ":cfg_keys"], z[name + ":cfg_vals"])}
+    lc = O.LlamaConfigLite(**kw)
+    seed, B, T, left = [int(v) for v in z[name + ":spec"]]
+    sd = O.init_llama_weights(lc, seed=seed)
+    x, am, pos = O.llama_inputs(lc, seed, B, T, "left" if left else "right")
+    return lc, sd, x, am, pos, _t(z[name + ":hidden"]), _t(z[name + ":logits"])
+
+
+@pytest.mark.parametrize("name", LLAMA_NAMES)
+def test_llama_prefill_matches_hf(golden_dir, name):
+    """oracle.llama_forward against HuggingFace LlamaForCausalLM's outputs (the `self.model` + `self.lm_head` of setokim_llama.py:130-143)
+    at every position that is a token (padded positions carry arbitrary values in HF and are masked out of the loss, :149-152)."""
+    lc, sd, x, am, pos, hidden, logits = _llama_case(golden_dir, name)
+    h, lg = O.llama_forward(sd, lc, x, am, pos)
+    v = am.bool()
+    torch.testing.assert_close(h[v], hidden[v], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lg[v], logits[v], rtol=1e-5, atol=1e-5)

@@ -111,3 +111,22 @@ def test_splice_restatement_vs_reference_live(kw):
             assert (r is None) == (g is None)
             if r is not None:
                 assert r.dtype == g.dtype and torch.equal(r, g)
+
+
+def test_llama_restatement_vs_installed_hf_live():
+    """cfg 5: oracle.llama_forward against the installed HuggingFace LlamaForCausalLM (third-party arithmetic the reference calls at
+    setokim_llama.py:130-143), eager attention, fp32 — bit-equal on token positions."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    kw = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100)
+    lc = O.LlamaConfigLite(**kw)
+    sd = O.init_llama_weights(lc, seed=3)
+    cfg = LlamaConfig(**kw, rms_norm_eps=lc.rms_norm_eps, rope_theta=lc.rope_theta, attention_bias=False, mlp_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    m = LlamaForCausalLM(cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    for padding in ("right", "left"):
+        x, am, pos = O.llama_inputs(lc, 5, 3, 13, padding)
+        with torch.no_grad():
+            ref = m(inputs_embeds=x, attention_mask=am, position_ids=pos).logits
+        _, got = O.llama_forward(sd, lc, x, am, pos)
+        assert torch.equal(got[am.bool()], ref[am.bool()])
