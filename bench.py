@@ -52,6 +52,9 @@ WORKLOADS = {
                                "parameters: inner_encoder, inter_encoder, out): tower + head forward with saved activations, hand-written backward "
                                "from a synthetic dL/dtokens, per-module RCCL gradient all-reduce overlapped with the backward pass, AdamW on fp32 "
                                "master weights"),
+    "cfg5": (224, 32, False, "cfg5: full Setokim forward at Vicuna-7B dims (32 layers, hidden 4096, 32 heads x 128, SwiGLU 11008, vocab 32000; random-init "
+                              "bf16 weights): 32 images -> SeTok encode (cfg2 model) -> mm_in_projector -> splice into 512-token prompts -> LLM prefill -> "
+                              "logits at every position (setokim_llama.py:94-143, no loss)"),
     "cfg3": (224, 256, True, "cfg3: cfg2 encode + reconstruction decoder (SetokDeTokenizer: token_feat_dim 4096 -> Q-Former 768/12 heads/6 layers, "
                               "324 queries (image_size 256 / 14), cross-attention every 2nd layer -> 16 x ViT block 768/16 heads -> LayerNorm); "
                               "no loss (the reference's GANLoss path is out of scope)"),
@@ -190,12 +193,38 @@ def main():
     g = torch.Generator().manual_seed(3 + rank)
     images = torch.randn(B, 3, img, img, generator=g).to(device=dev, dtype=torch.bfloat16)   # resident in HBM
 
+    llm = None
+    if args.workload == "cfg5":
+        from setok_amd.llama import SetokimLlamaPrefill
+        lcfg = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                    num_key_value_heads=32, rms_norm_eps=1e-5, rope_theta=10000.0)
+        with torch.device(dev):
+            llm = SetokimLlamaPrefill(lcfg, vision_tower=tok, mm_in_projector=proj).to(torch.bfloat16)
+        gl = torch.Generator(device=dev).manual_seed(11)
+        for n_, p_ in llm.named_parameters():
+            if n_.startswith(("vision_tower.", "mm_in_projector.")):
+                continue
+            if p_.dim() == 2:
+                p_.data.normal_(0.0, 0.02, generator=gl)
+            else:
+                p_.data.fill_(1.0)
+        llm.eval()
+        T_TXT = 512
+        ids = torch.randint(0, 32000, (B, T_TXT), generator=torch.Generator().manual_seed(5 + rank))
+        ids[:, 17] = -200                                         # one image placeholder per prompt (IMAGE_TOKEN_INDEX)
+        ids = ids.to(dev)
+        amask = torch.ones(B, T_TXT, dtype=torch.bool, device=dev)
+        log("LLM on device")
     trainer = None
     if args.workload == "cfg4":
         from setok_amd.training import HeadTrainer
         trainer = HeadTrainer(tok, lr=1e-5, weight_decay=0.0)
 
     def step():
+        if llm is not None:
+            logits, _, _ = llm(input_ids=ids, attention_mask=amask, comp_images=images)
+            step.logits = logits
+            return llm._last_features
         if trainer is not None:
             tokens, ctx = trainer.forward(images)
             trainer.backward(ctx, tokens.packed * 1e-3)          # dL/dtokens of L = 5e-4 |tokens|^2, standing in for the projector / LLM

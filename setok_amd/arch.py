@@ -85,6 +85,7 @@ class SetokimVisionMixin:
         if type(images) is list or images.ndim == 5:                                                   # :222-225
             images = torch.stack([image for image in images], dim=0)
         image_features = self.encode_images(images)
+        self._last_features = image_features                                                           # kept for callers that report token counts
         cfg = getattr(self, "config", None)
         pos, am, embeds, new_labels = splice_multimodal(
             input_ids, position_ids, attention_mask, labels, image_features, self.get_model().embed_tokens.weight,

@@ -145,6 +145,7 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
         """Returns (logits, new_labels, attention_mask): logits (B, T', vocab) — or (B, vocab) for every sequence's last token with
         `last_token_only` (what a generation step after the prefill needs) — on the spliced sequence of length T'."""
         new_labels = labels
+        self._last_features = None
         if inputs_embeds is None:
             _, position_ids, attention_mask, _, inputs_embeds, new_labels = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, None, labels, comp_images)
