@@ -280,3 +280,30 @@ def test_dataset_side_encode_batch_equals_per_sample(golden_dir):
     for i in range(5):
         one = tok.encode(images[i])
         assert one.shape[0] == num[i] and torch.equal(one, feats[i])
+
+
+def test_cfg1_vitb16_fixed_k32_fp32():
+    """BASELINE config 1: one 224^2 image, ViT-B/16 tower (768 / 12 layers / 12 heads, 196 patches), FIXED k = 32 clusters (a threshold no
+    score reaches -> the top-32 fallback, tokenizer.py:105-107), fp32 — the GPU path against the CPU oracle on the same seeded weights."""
+    vc = O.VitConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, image_size=224, patch_size=16)
+    hc = O.HeadConfig(hidden_dim=768, token_feat_dim=4096, min_cluster_num=32, threshold=1e9, nheads=2, dim_feedforward=3072)
+    sd = O.init_tower_weights(vc, 0); sd.update(O.init_head_weights(hc, 1))
+    tok = SetokTokenizer(vision_tower=dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, image_size=224,
+                                           patch_size=16), mm_vision_select_layer=-2, hidden_dim=768, token_feat_dim=4096, min_cluster_num=32,
+                         threshold=1e9, nheads=2, dim_feedforward=3072)
+    assert not tok.load_state_dict(sd, strict=False).unexpected_keys
+    tok = tok.to(DEV).eval()
+    g = torch.Generator().manual_seed(21)
+    image = torch.randn(1, 3, 224, 224, generator=g)
+    toks, idx, score = tok(image.to(DEV))
+    feats_ref, ref = O.encode(sd, vc, hc, image)
+    assert toks[0].shape == (32, 4096) and ref[0].tokens.shape == (32, 4096) and tuple(idx.shape) == (1, 196)
+    assert _rel(tok.image_feature_encoder(image.to(DEV)), feats_ref) < TOL
+    x = feats_ref[0] + O.pos_encoding_2d(14, 14, 768)
+    sens = O.cluster_sensitivity(x, 32, 1e9, 32, ulps=256.0)
+    same = idx[0].cpu() == ref[0].idx_cluster
+    if sens["centres_certain"]:
+        assert bool((same | ~sens["assign_certain"]).all())
+        if bool(same.all()):
+            assert _rel(toks[0], ref[0].tokens) < TOL
+    print("cfg1 ViT-B/16 k=32: tokens with a different cluster id:", int((~same).sum()), "of 196; centres certain:", bool(sens["centres_certain"]))
