@@ -37,32 +37,69 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
 }
 
 // ---- rotary embedding on q and k of [q | k | v] rows -----------------------------------------------------------------------------------------
+// One thread per (row, chunk of V dims of the first half): cos / sin of its V angles are computed ONCE and reused for the row's 2H heads
+// (the angle depends on the position and the dim only), every head costs two 16-byte loads and two 16-byte stores.
 template <typename T>
-__global__ void rope_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Dh, float log2_theta) {
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Dh, float log2_theta) {
+    constexpr int V = Elem<T>::VEC;
+    const int half = Dh >> 1, chunks = half / V;
+    const int64_t total = (int64_t)rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const int64_t r = i / chunks;
+        const float p = (float)pos[r];
+        float c[V], s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float ang = p * (1.0f / exp2f(log2_theta * (float)(2 * (ch * V + e)) / (float)Dh));
+            c[e] = rnd<T>(cosf(ang)); s[e] = rnd<T>(sinf(ang));
+        }
+        T* base = qkv + r * (int64_t)(3 * H * Dh) + ch * V;
+        for (int hh = 0; hh < 2 * H; ++hh) {                              // q heads, then k heads: contiguous in [q | k | v]
+            T* q = base + (int64_t)hh * Dh;
+            float x1[V], x2[V], o1[V], o2[V];
+            ld_vec<T>(q, x1); ld_vec<T>(q + half, x2);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                o1[e] = rnd<T>(x1[e] * c[e]) + rnd<T>(-x2[e] * s[e]);      // q * cos + rotate_half(q) * sin, each op rounded
+                o2[e] = rnd<T>(x2[e] * c[e]) + rnd<T>(x1[e] * s[e]);
+            }
+            st_vec<T>(q, o1); st_vec<T>(q + half, o2);
+        }
+    }
+}
+
+// scalar fallback for head dims whose half is not a multiple of the vector width
+template <typename T>
+__global__ void rope_scalar_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Dh, float log2_theta) {
     const int half = Dh >> 1;
     const int64_t total = (int64_t)rows * 2 * H * half;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % half);
-        const int hh = (int)((i / half) % (2 * H));                      // head index over q then k
+        const int hh = (int)((i / half) % (2 * H));
         const int64_t r = i / ((int64_t)half * 2 * H);
-        const float inv_freq = 1.0f / exp2f(log2_theta * (float)(2 * d) / (float)Dh);
-        const float ang = (float)pos[r] * inv_freq;
+        const float ang = (float)pos[r] * (1.0f / exp2f(log2_theta * (float)(2 * d) / (float)Dh));
         const float c = rnd<T>(cosf(ang)), s = rnd<T>(sinf(ang));
         T* p = qkv + r * (int64_t)(3 * H * Dh) + (int64_t)hh * Dh + d;
         const float x1 = (float)p[0], x2 = (float)p[half];
-        p[0] = (T)(rnd<T>(x1 * c) + rnd<T>(-x2 * s));                     // q * cos + rotate_half(q) * sin, each op rounded
+        p[0] = (T)(rnd<T>(x1 * c) + rnd<T>(-x2 * s));
         p[half] = (T)(rnd<T>(x2 * c) + rnd<T>(x1 * s));
     }
 }
 
-// ---- SwiGLU ------------------------------------------------------------------------------------------------------------------------------------
+// ---- SwiGLU: V elements per thread, 16-byte accesses -----------------------------------------------------------------------------------------
 template <typename T>
-__global__ void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int64_t rows, int F) {
-    const int64_t total = rows * F;
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int64_t rows, int F) {
+    constexpr int V = Elem<T>::VEC;
+    const int chunks = F / V;
+    const int64_t total = rows * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / F; const int c = (int)(i % F);
-        const float g = (float)gu[r * 2 * F + c], u = (float)gu[r * 2 * F + F + c];
-        out[i] = (T)(rnd<T>(g / (1.0f + expf(-g))) * u);
+        const int64_t r = i / chunks; const int c = (int)(i % chunks) * V;
+        float g[V], u[V];
+        ld_vec<T>(gu + r * 2 * F + c, g); ld_vec<T>(gu + r * 2 * F + F + c, u);
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = rnd<T>(g[e] / (1.0f + expf(-g[e]))) * u[e];
+        st_vec<T>(out + r * F + c, g);
     }
 }
 
@@ -260,20 +297,28 @@ extern "C" int setok_rope(void* stream, int dtype, void* qkv, const int64_t* pos
     SETOK_CHECK_ARG(rows >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0 && theta > 0.f, "setok_rope: bad shape");
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)rows * H * Dh;
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     const float l2 = log2f(theta);
-    LL_DISPATCH("setok_rope", (rope_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Dh, l2)),
-                (rope_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Dh, l2)));
+    const int V = dtype == SETOK_BF16 ? 8 : 4;
+    if ((Dh / 2) % V == 0) {
+        const int64_t total = (int64_t)rows * (Dh / 2 / V);
+        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        LL_DISPATCH("setok_rope", (rope_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Dh, l2)),
+                    (rope_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Dh, l2)));
+    } else {
+        const int64_t total = (int64_t)rows * H * Dh;
+        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        LL_DISPATCH("setok_rope", (rope_scalar_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Dh, l2)),
+                    (rope_scalar_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Dh, l2)));
+    }
     SETOK_CHECK_LAUNCH("setok_rope");
     return SETOK_OK;
 }
 
 extern "C" int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_t rows, int F) {
-    SETOK_CHECK_ARG(gate_up && out && rows >= 0 && F > 0, "setok_swiglu: bad operand");
+    SETOK_CHECK_ARG(gate_up && out && rows >= 0 && F > 0 && F % 8 == 0, "setok_swiglu: bad operand (F must be a multiple of 8)");
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = rows * F;
+    const int64_t total = rows * (F / (dtype == SETOK_BF16 ? 8 : 4));
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     LL_DISPATCH("setok_swiglu", (swiglu_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)gate_up, (bf16*)out, rows, F)),
                 (swiglu_kernel<float><<<grid, 256, 0, s>>>((const float*)gate_up, (float*)out, rows, F)));
