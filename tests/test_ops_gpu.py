@@ -325,6 +325,32 @@ def test_cluster_batched_equals_per_image_and_bf16_runs():
                                O.cluster_sensitivity(xb[i].float(), 8, 0.5, 64))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,k,mcn,thr", [(1024, 256, 64, 64, 0.5), (1024, 256, 64, 64, 1e9), (4, 64, 2, 2, 0.5), (1, 64, 1, 1, 0.5), (576, 1024, 64, 64, 0.2)])
+def test_cluster_size_limits(dt, N, C, k, mcn, thr):
+    """The largest supported grid (32 x 32 = 1024 patches: 64 lanes x 16 register slots per distance row), the smallest (2 x 2, and a single
+    patch), and the 336^2 grid, fp32 and bf16 (bf16: the dedicated Gram kernel incl. its column-chunk loop for N > 256), against the oracle on
+    the same (rounded) features; decisions the fp64 margin analysis calls certain must be equal."""
+    xs = torch.stack([O.planted_features(N, C, max(1, min(N, 5)) + i, seed=70 + i) for i in range(2)]).to(dt)
+    idx, score, index_down, counts = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), 2, N, k, thr, mcn)
+    for i in range(2):
+        r = O.cluster_dpc_knn(xs[i].float(), k, thr, mcn)
+        L = int(counts[i])
+        assert idx.dtype == torch.int64 and int(idx[i].max()) < L and int(idx[i].min()) >= 0
+        O.check_cluster_parity(index_down[i, :L].cpu(), idx[i].cpu(), r.index_down, r.idx_cluster,
+                               O.cluster_sensitivity(xs[i].float(), k, thr, mcn))
+
+
+def test_cluster_argument_errors():
+    x = torch.zeros(1025, 64, device=DEV)
+    with pytest.raises(Exception):
+        ops.cluster_dpc_knn(x, 1, 1025, 8, 0.5, 8)                 # N > 1024
+    with pytest.raises(Exception):
+        ops.cluster_dpc_knn(x[:16], 1, 16, 17, 0.5, 8)             # k > N: torch.topk would raise in the reference
+    with pytest.raises(Exception):
+        ops.cluster_dpc_knn(x[:16], 1, 16, 4, 0.5, 17)             # min_cluster_num > N
+
+
 # ---------------------------------------------------------------------------------------------
 # sort / gather / segment mean
 # ---------------------------------------------------------------------------------------------
