@@ -31,6 +31,8 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0              # HBM3E, MI355X_MICROARCH.md
+MFMA_ONLY_RANDOM_TFLOPS = 1847.0   # measured: tools/micro/mfma_peak.hip (register-resident MFMA loop, random bf16 operands, power-managed
+                                   # to 1.95 GHz / 1.28 kW; 2449 TFLOP/s at 2.40 GHz on all-zero operands) — profiles/r01_mfma_peak.log
 B_PER_GPU, IMG, PATCH = 256, 224, 14
 THRESHOLD, KNN = 0.125, 64         # dyn-k fires with seeded random-init features
 
@@ -294,6 +296,8 @@ def main():
             res["roofline_clustering"] = {"bound": "hbm", "kernel": "setok_cluster_dpc_knn (Gram + kNN density + delta/score + select + assign)",
                                           "achieved": round(c_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(c_gbs / PEAK_HBM_GBS, 4),
                                           "ms_per_call": round(c_ms, 4), "share_of_step": round(c_ms * len(clus) / (dt * 1e3), 4)}
+        res["roofline"]["mfma_only_random_operands_tflops"] = MFMA_ONLY_RANDOM_TFLOPS
+        res["roofline"]["frac_of_mfma_only_random"] = round(achieved / MFMA_ONLY_RANDOM_TFLOPS, 4)
         if telemetry:
             res["roofline"].update(telemetry)
             if telemetry.get("sclk_mhz_under_load"):
