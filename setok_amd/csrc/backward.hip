@@ -172,12 +172,14 @@ __device__ inline void seg_of(const int32_t* seg_offsets, int n_segs, int seg_le
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ seg_offsets, int n_segs, int seg_len,
                                                         const T* __restrict__ o, const T* __restrict__ dout, T* __restrict__ dqkv,
-                                                        float* __restrict__ lse, float* __restrict__ dsum, int rows, int H, int Dh, float scale) {
+                                                        float* __restrict__ lse, float* __restrict__ dsum, int rows, int H, int Dh, float scale,
+                                                        int skip_long) {
     constexpr int V = Elem<T>::VEC;
     const int row = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     int s0, s1;
     seg_of<T>(seg_offsets, n_segs, seg_len, rows, row, s0, s1);
     if (row < s0 || row >= s1) return;
+    if (skip_long && s1 - s0 > 32) return;                              // the segment-owning MFMA kernels' share (attn_seg_bwd.hip)
     const int64_t C = (int64_t)H * Dh, ld = 3 * C;
     const int nc = (Dh + 64 * V - 1) / (64 * V);
     float q[AT_MAXC][V], dq[AT_MAXC][V], dO[AT_MAXC][V], buf[V];
@@ -244,12 +246,13 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const T* __restrict__ qk
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ seg_offsets, int n_segs, int seg_len,
                                                          const T* __restrict__ dout, T* __restrict__ dqkv, const float* __restrict__ lse,
-                                                         const float* __restrict__ dsum, int rows, int H, int Dh, float scale) {
+                                                         const float* __restrict__ dsum, int rows, int H, int Dh, float scale, int skip_long) {
     constexpr int V = Elem<T>::VEC;
     const int row = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     int s0, s1;
     seg_of<T>(seg_offsets, n_segs, seg_len, rows, row, s0, s1);
     if (row < s0 || row >= s1) return;
+    if (skip_long && s1 - s0 > 32) return;
     const int64_t C = (int64_t)H * Dh, ld = 3 * C;
     const int nc = (Dh + 64 * V - 1) / (64 * V);
     float k[AT_MAXC][V], v[AT_MAXC][V], dk[AT_MAXC][V], dv[AT_MAXC][V], qb[AT_MAXC][V], ob[AT_MAXC][V];
@@ -333,6 +336,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 }  // namespace
 
+int setok_attention_bwd_seg_bf16(hipStream_t s, const bf16* qkv, const int32_t* seg_offsets, int n_segs, const bf16* out, const bf16* dout,
+                                 bf16* dqkv, float* lse_ws, float* d_ws, int H, int Dh, float scale);       // attn_seg_bwd.hip
+
 #define DISPATCH_T(NAME, CALL_BF16, CALL_F32)                                  \
     if (dtype == SETOK_BF16) { CALL_BF16; }                                    \
     else if (dtype == SETOK_F32) { CALL_F32; }                                 \
@@ -410,12 +416,18 @@ extern "C" int setok_attention_bwd(void* stream, int dtype, const void* qkv, con
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     float* lse = ws; float* dsum = ws + (int64_t)rows * H;
+    int skip_long = 0;
+    if (dtype == SETOK_BF16 && seg_offsets && Dh == 512 && seg_len > 32) {      // long segments: the segment-owning MFMA kernels
+        const int rc = setok_attention_bwd_seg_bf16(s, (const bf16*)qkv, seg_offsets, n_segs, (const bf16*)out, (const bf16*)dout, (bf16*)dqkv, lse, dsum,
+                                                    H, Dh, scale);
+        if (rc == SETOK_OK) skip_long = 1; else if (rc != SETOK_EUNSUPPORTED) return rc;
+    }
     dim3 grid(rows, H);
     DISPATCH_T("setok_attention_bwd",
-               (attn_bwd_q_kernel<bf16><<<grid, 64, 0, s>>>((const bf16*)qkv, seg_offsets, n_segs, seg_len, (const bf16*)out, (const bf16*)dout, (bf16*)dqkv, lse, dsum, rows, H, Dh, scale),
-                attn_bwd_kv_kernel<bf16><<<grid, 64, 0, s>>>((const bf16*)qkv, seg_offsets, n_segs, seg_len, (const bf16*)dout, (bf16*)dqkv, lse, dsum, rows, H, Dh, scale)),
-               (attn_bwd_q_kernel<float><<<grid, 64, 0, s>>>((const float*)qkv, seg_offsets, n_segs, seg_len, (const float*)out, (const float*)dout, (float*)dqkv, lse, dsum, rows, H, Dh, scale),
-                attn_bwd_kv_kernel<float><<<grid, 64, 0, s>>>((const float*)qkv, seg_offsets, n_segs, seg_len, (const float*)dout, (float*)dqkv, lse, dsum, rows, H, Dh, scale)));
+               (attn_bwd_q_kernel<bf16><<<grid, 64, 0, s>>>((const bf16*)qkv, seg_offsets, n_segs, seg_len, (const bf16*)out, (const bf16*)dout, (bf16*)dqkv, lse, dsum, rows, H, Dh, scale, skip_long),
+                attn_bwd_kv_kernel<bf16><<<grid, 64, 0, s>>>((const bf16*)qkv, seg_offsets, n_segs, seg_len, (const bf16*)dout, (bf16*)dqkv, lse, dsum, rows, H, Dh, scale, skip_long)),
+               (attn_bwd_q_kernel<float><<<grid, 64, 0, s>>>((const float*)qkv, seg_offsets, n_segs, seg_len, (const float*)out, (const float*)dout, (float*)dqkv, lse, dsum, rows, H, Dh, scale, 0),
+                attn_bwd_kv_kernel<float><<<grid, 64, 0, s>>>((const float*)qkv, seg_offsets, n_segs, seg_len, (const float*)dout, (float*)dqkv, lse, dsum, rows, H, Dh, scale, 0)));
     SETOK_CHECK_LAUNCH("setok_attention_bwd");
     return SETOK_OK;
 }

@@ -91,7 +91,7 @@ def test_gelu_bwd(dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("H,Dh,lens", [(2, 32, [1, 7, 64, 3, 20]), (2, 512, [5, 1, 9]), (4, 16, [130, 2])])
+@pytest.mark.parametrize("H,Dh,lens", [(2, 32, [1, 7, 64, 3, 20]), (2, 512, [5, 1, 9]), (4, 16, [130, 2]), (2, 512, [40, 130, 7, 33, 64, 32, 229])])
 def test_attention_bwd_ragged(dt, tol, H, Dh, lens):
     offs = np.concatenate([[0], np.cumsum(lens)]).tolist()
     C = H * Dh
