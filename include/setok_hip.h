@@ -185,8 +185,11 @@ int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* e
 /* out[c * ldo + r] = x[r * ldx + c] for r < rows, c < cols; out rows are zero-filled for r in [rows, ldo) (pads the contraction
  * dimension of the following GEMM to its K granule).  chunk > 0 (a divisor of ldo): the padded row range is cut into ldo / chunk
  * pieces stored one after the other, each a (cols, chunk) matrix — the operand layout of a split-K batched dW GEMM whose
- * fp32 partial products are then summed in a fixed order (setok_colsum over the batch). */
-int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int chunk);
+ * fp32 partial products are then summed in a fixed order (setok_colsum over the batch).  colsum_partial (optional): fp32
+ * [ceil(ldo / 64) * cols]; row b receives the column sums of x over rows [64 b, 64 b + 64) — summing these rows (setok_colsum, fp32)
+ * gives the bias gradient without another pass over dY. */
+int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int chunk,
+                    float* colsum_partial);
 
 /* out[c] (+)= sum_r x[r, c] (bias gradients).  ws: fp32[ws_rows * cols], ws_rows >= 1 (more rows = more parallelism). */
 int setok_colsum(void* stream, int dtype, const void* x, int rows, int cols, float* out, int accumulate, float* ws, int ws_rows);

@@ -11,23 +11,65 @@ namespace {
 
 // ---- out[c * ldo + r] = x[r * ldx + c]; rows r in [rows, ldo) of the output are written as zeros.  With chunk > 0 the padded row
 //      range is cut into ldo / chunk chunks stored one after the other, each as a (cols, chunk) matrix: the split-K operand layout of
-//      a batched dW GEMM (out[((r / chunk) * cols + c) * chunk + r % chunk]) ---------------------------------------------------------
+//      a batched dW GEMM (out[((r / chunk) * cols + c) * chunk + r % chunk]).
+//      64 x 64 tiles through LDS, 16-byte global accesses on both sides (V = 8 bf16 / 4 fp32 per access).  Optionally the tile's column
+//      sums over its 64 rows go to colsum[blockIdx.x][c] (fp32, fixed order): the bias gradient falls out of the pass that transposes dY.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, int64_t ldx, int rows, int cols, T* __restrict__ out,
-                                                        int64_t ldo, int chunk) {
-    __shared__ T tile[64][65];
+                                                        int64_t ldo, int chunk, float* __restrict__ colsum) {
+    constexpr int V = Elem<T>::VEC;                // elements per 16-byte access
+    constexpr int CPR = 64 / V;                    // 16-byte pieces per 64-element tile row
+    constexpr int RPP = 256 / CPR;                 // tile rows covered per pass of the 256 threads
+    __shared__ T tile[64][64 + 2];                 // +2 elements: the transposed 2-/4-byte reads of 8 (4) consecutive rows spread over the banks
+    __shared__ float csum[RPP][64];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < rows && c < cols) ? x[(int64_t)r * ldx + c] : (T)0.f;
+    const int tid = threadIdx.x;
+    const int pc = tid % CPR, pr = tid / CPR;
+    const bool vec_in = (ldx % V == 0) && (c0 + 64 <= cols);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    for (int i = pr; i < 64; i += RPP) {
+        const int r = r0 + i, c = c0 + pc * V;
+        float v[V];
+        if (r < rows && vec_in) ld_vec<T>(x + (int64_t)r * ldx + c, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = (r < rows && c + e < cols) ? Elem<T>::ld(x + (int64_t)r * ldx + c + e) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) { tile[i][pc * V + e] = (T)v[e]; acc[e] += v[e]; }
+    }
+    if (colsum) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) csum[pr][pc * V + e] = acc[e];
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < cols && r < ldo) {
-            if (chunk > 0) out[((int64_t)(r / chunk) * cols + c) * chunk + r % chunk] = tile[tx][i];
-            else out[(int64_t)c * ldo + r] = tile[tx][i];
+    if (colsum && tid < 64 && c0 + tid < cols) {
+        float sum = 0.f;
+        for (int k = 0; k < RPP; ++k) sum += csum[k][tid];
+        colsum[(int64_t)blockIdx.x * cols + c0 + tid] = sum;
+    }
+    // output: row c of the transposed matrix holds 64 consecutive r: CPR pieces of V elements
+    const bool vec_out = (ldo % V == 0) && (chunk == 0 || chunk % V == 0);
+    for (int i = pr; i < 64; i += RPP) {
+        const int c = c0 + i, r = r0 + pc * V;
+        if (c >= cols || r >= ldo) continue;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = (float)tile[pc * V + e][i];
+        if (vec_out && r + V <= ldo) {
+            T* dst = chunk > 0 ? out + ((int64_t)(r / chunk) * cols + c) * chunk + r % chunk : out + (int64_t)c * ldo + r;
+            st_vec<T>(dst, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int rr = r + e;
+                if (rr < ldo) {
+                    T* dst = chunk > 0 ? out + ((int64_t)(rr / chunk) * cols + c) * chunk + rr % chunk : out + (int64_t)c * ldo + rr;
+                    Elem<T>::st(dst, v[e]);
+                }
+            }
         }
     }
 }
@@ -344,7 +386,8 @@ int setok_attention_bwd_seg_bf16(hipStream_t s, const bf16* qkv, const int32_t* 
     else if (dtype == SETOK_F32) { CALL_F32; }                                 \
     else return setok_fail(SETOK_EINVAL, NAME ": bad dtype %d", dtype);
 
-extern "C" int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int chunk) {
+extern "C" int setok_transpose(void* stream, int dtype, const void* x, int64_t ldx, int rows, int cols, void* out, int64_t ldo, int chunk,
+                               float* colsum_partial) {
     SETOK_CHECK_ARG(x && out, "setok_transpose: null operand");
     SETOK_CHECK_ARG(rows >= 0 && cols > 0 && ldx >= cols && ldo >= rows, "setok_transpose: bad shape rows=%d cols=%d ldx=%lld ldo=%lld", rows, cols,
                     (long long)ldx, (long long)ldo);
@@ -352,8 +395,8 @@ extern "C" int setok_transpose(void* stream, int dtype, const void* x, int64_t l
     if (ldo == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv((int)ldo, 64), cdiv(cols, 64));
-    DISPATCH_T("setok_transpose", (transpose_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, ldx, rows, cols, (bf16*)out, ldo, chunk)),
-               (transpose_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ldx, rows, cols, (float*)out, ldo, chunk)));
+    DISPATCH_T("setok_transpose", (transpose_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, ldx, rows, cols, (bf16*)out, ldo, chunk, colsum_partial)),
+               (transpose_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ldx, rows, cols, (float*)out, ldo, chunk, colsum_partial)));
     SETOK_CHECK_LAUNCH("setok_transpose");
     return SETOK_OK;
 }
@@ -362,7 +405,7 @@ extern "C" int setok_colsum(void* stream, int dtype, const void* x, int rows, in
     SETOK_CHECK_ARG(x && out && ws, "setok_colsum: null operand");
     SETOK_CHECK_ARG(rows >= 0 && cols > 0 && ws_rows >= 1, "setok_colsum: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    int chunks = cdiv(max(rows, 1), 512);
+    int chunks = cdiv(max(rows, 1), rows > 16384 ? 512 : 32);        // enough workgroups to fill the chip also for short inputs (per-tile partial sums)
     if (chunks > ws_rows) chunks = ws_rows;
     const int rpc = cdiv(max(rows, 1), chunks);
     chunks = cdiv(max(rows, 1), rpc);

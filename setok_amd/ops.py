@@ -264,20 +264,24 @@ def splice_rows(src: Tensor, embed_table: Tensor, image_tokens: Optional[Tensor]
 
 
 # ---- backward pass of the trainable head (csrc/backward.hip) ----------------------------------------------------------------
-def transpose(x: Tensor, pad_to: int = 1, splits: int = 1) -> Tensor:
+def transpose(x: Tensor, pad_to: int = 1, splits: int = 1, with_colsum: bool = False):
     """(rows, cols) -> (cols, P) with P = rows zero-padded to a multiple of pad_to: the A / W operand of a dW = dY^T X GEMM.
-    splits > 1: P is padded to splits * chunk (chunk a multiple of pad_to) and the result is (splits, cols, chunk) — the split-K layout."""
+    splits > 1: P is padded to splits * chunk (chunk a multiple of pad_to) and the result is (splits, cols, chunk) — the split-K layout.
+    with_colsum: also returns the fp32 column sums of x (the bias gradient when x is dY), computed inside the same pass."""
     rows, cols = x.shape
     assert x.is_contiguous()
     if splits <= 1:
-        ldo = round_up(max(rows, 1), pad_to)
+        ldo, chunk = round_up(max(rows, 1), pad_to), 0
         out = torch.empty((cols, ldo), dtype=x.dtype, device=x.device)
-        _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), ldo, 0)
+    else:
+        chunk = round_up((max(rows, 1) + splits - 1) // splits, pad_to)
+        ldo = splits * chunk
+        out = torch.empty((splits, cols, chunk), dtype=x.dtype, device=x.device)
+    part = torch.empty(((ldo + 63) // 64, cols), dtype=torch.float32, device=x.device) if with_colsum else None
+    _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), ldo, chunk, _p(part))
+    if not with_colsum:
         return out
-    chunk = round_up((max(rows, 1) + splits - 1) // splits, pad_to)
-    out = torch.empty((splits, cols, chunk), dtype=x.dtype, device=x.device)
-    _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), splits * chunk, chunk)
-    return out
+    return out, colsum(part)
 
 
 def linear_tn(aT: Tensor, bT: Tensor) -> Tensor:

@@ -42,9 +42,9 @@ def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[s
     # batched partial products summed in a fixed order — enough workgroups to fill the chip, still deterministic
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = max(1, min(16, 1024 // max(tiles, 1), M // 2048))
-    dyT, xT = ops.transpose(dy, pad, S), ops.transpose(x, pad, S)
+    (dyT, db), xT = ops.transpose(dy, pad, S, with_colsum=True), ops.transpose(x, pad, S)      # the bias gradient falls out of dY's transpose
     grads[name + ".weight"] = ops.linear_tn(dyT, xT)
-    grads[name + ".bias"] = ops.colsum(dy)
+    grads[name + ".bias"] = db
     if not need_dx:
         return None
     wT = ops.transpose(w.contiguous())                            # (K, N)

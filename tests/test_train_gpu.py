@@ -42,6 +42,8 @@ def test_transpose_pads_with_zeros(dt, rows, cols, pad):
     out = ops.transpose(x.to(DEV), pad).cpu()
     ldo = (rows + pad - 1) // pad * pad
     assert out.shape == (cols, ldo) and torch.equal(out[:, :rows], x.t()) and float(out[:, rows:].abs().max() if ldo > rows else 0) == 0.0
+    out2, cs = ops.transpose(x.to(DEV), pad, with_colsum=True)
+    assert torch.equal(out2.cpu(), out) and _rel(cs, x.double().sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-5)])
