@@ -187,8 +187,15 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                     af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
                 }
                 if (LOAD && do_load) {
-                    dma16(a_src[ks] + k_next, sb + ks * 8192);
-                    dma16(b_src[ks] + k_next, sb + BOFF + ks * 8192);
+                    // the whole next K-tile is requested in the first two k-steps (two A and two B pieces per thread each): the
+                    // requests then have two more k-steps to land before the vmcnt wait at the top of the next K-tile
+                    // (measured within one box, alternating: +1..2 % at K = 1024, +3..5 % at K = 4096 against one piece pair per k-step)
+                    if (ks < 2) {
+                        dma16(a_src[2 * ks] + k_next, sb + (2 * ks) * 8192);
+                        dma16(a_src[2 * ks + 1] + k_next, sb + (2 * ks + 1) * 8192);
+                        dma16(b_src[2 * ks] + k_next, sb + BOFF + (2 * ks) * 8192);
+                        dma16(b_src[2 * ks + 1] + k_next, sb + BOFF + (2 * ks + 1) * 8192);
+                    }
                 }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
