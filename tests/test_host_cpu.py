@@ -51,3 +51,73 @@ def test_tokenizer_mirror_keys_match_oracle_init():
 def test_splice_constants_match_reference_constants():
     from setok_amd import arch
     assert (arch.IGNORE_INDEX, arch.IMAGE_TOKEN_INDEX, arch.TARGET_TOKEN_INDEX) == (O.IGNORE_INDEX, O.IMAGE_TOKEN_INDEX, O.TARGET_TOKEN_INDEX) == (-100, -200, -300)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# checkpoint hand-over with the reference's key names (setokim_arch.py:94-99, :115-120; setokim_trainer.py:234-251)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _small_tok(seed):
+    from setok_amd import SetokTokenizer
+    torch.manual_seed(seed)
+    vc = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, image_size=112, patch_size=14)
+    tok = SetokTokenizer(vision_tower=vc, hidden_dim=64, token_feat_dim=96, min_cluster_num=8, nheads=2, dim_feedforward=128)
+    with torch.no_grad():
+        for p in tok.parameters():
+            p.copy_(torch.randn_like(p))
+    return tok
+
+
+def test_select_by_keyword_is_the_references_get_w():
+    from setok_amd.checkpoint import select_by_keyword
+    w = {"tokenizer.out.weight": torch.ones(1), "model.tokenizer.out.bias": torch.zeros(1), "detokenizer.decoder_norm.weight": torch.full((1,), 2.0),
+         "loss.logit_scale": torch.full((1,), 3.0)}
+    got = select_by_keyword(w, "tokenizer")
+    # keys CONTAINING the keyword, cut after its first occurrence — detokenizer keys come along (reference quirk, strict=False drops them)
+    assert set(got) == {"out.weight", "out.bias", "decoder_norm.weight"}
+    assert got["decoder_norm.weight"].item() == 2.0
+    with pytest.raises(IndexError):
+        select_by_keyword({"tokenizer_scale": torch.ones(1)}, "tokenizer")          # contains the keyword, not `keyword.`: the reference raises too
+
+
+def test_tokenizer_checkpoint_round_trip(tmp_path):
+    from setok_amd import checkpoint as C
+    a, b = _small_tok(0), _small_tok(1)
+    sd = C.save_tokenizer_checkpoint(a, tmp_path / "setok.bin")
+    assert all(k.startswith("tokenizer.") for k in sd) and not any("image_feature_encoder" in k for k in sd)
+    assert "tokenizer.inner_encoder.layers.0.0.weight" in sd and "tokenizer.out.weight" in sd
+    missing, unexpected = C.load_pretrained_tokenizer(b, tmp_path / "setok.bin")
+    assert unexpected == [] and all(k.startswith("image_feature_encoder.") for k in missing)        # the frozen tower is not in the file
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q) == (not n.startswith("image_feature_encoder.")), n
+    full = C.tokenizer_checkpoint(a, include_tower=True)
+    assert any(k.startswith("tokenizer.image_feature_encoder.") for k in full)
+    assert C.load_pretrained_tokenizer(b, full).missing_keys == []
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+
+
+def test_adapter_checkpoint_round_trip(tmp_path):
+    from setok_amd import build_vision_projector, checkpoint as C
+
+    class Inner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mm_in_projector = build_vision_projector("mlp2x_gelu", 32, 48)
+            self.embed_tokens = torch.nn.Embedding(10, 48)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Inner()
+            self.lm_head = torch.nn.Linear(48, 10, bias=False)
+
+    torch.manual_seed(0)
+    m = Model()
+    path = C.save_adapter_checkpoint(m, tmp_path / "checkpoint-10")
+    assert path.endswith("mm_projector.bin")
+    sd = torch.load(path)
+    assert set(sd) == {f"model.mm_in_projector.{i}.{w}" for i in (0, 2) for w in ("weight", "bias")}      # names untouched, nothing else saved
+    torch.manual_seed(1)
+    p = build_vision_projector("mlp2x_gelu", 32, 48)
+    res = C.load_pretrained_projector(p, path)
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    assert all(torch.equal(x, y) for x, y in zip(p.parameters(), m.model.mm_in_projector.parameters()))

@@ -130,3 +130,36 @@ def test_llama_restatement_vs_installed_hf_live():
             ref = m(inputs_embeds=x, attention_mask=am, position_ids=pos).logits
         _, got = O.llama_forward(sd, lc, x, am, pos)
         assert torch.equal(got[am.bool()], ref[am.bool()])
+
+
+def test_checkpoint_key_names_load_in_the_reference_and_back(tok, tmp_path):
+    """A stage-1 checkpoint written by setok_amd.checkpoint loads in the reference's SetokTokenizer through the reference's own
+    `get_w(weights, 'tokenizer')` + `load_state_dict(strict=False)` (setokim_arch.py:94-99), and a reference-side checkpoint loads here."""
+    from setok_amd import SetokTokenizer, checkpoint as C
+    torch.manual_seed(5)
+    vc = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=112, patch_size=14)
+    mine = SetokTokenizer(vision_tower=vc, hidden_dim=64, token_feat_dim=96, min_cluster_num=8, nheads=2, dim_feedforward=128)
+    with torch.no_grad():
+        for n, p in mine.named_parameters():
+            if not n.startswith("image_feature_encoder."):
+                p.copy_(torch.randn_like(p))
+    path = tmp_path / "setok_stage1.bin"
+    C.save_tokenizer_checkpoint(mine, path)
+
+    import copy
+    ref = copy.deepcopy(tok)
+    weights = torch.load(path, map_location="cpu")
+    get_w = lambda weights, keyword: {k.split(keyword + '.')[1]: v for k, v in weights.items() if keyword in k}      # as the reference spells it
+    res = ref.load_state_dict(get_w(weights, "tokenizer"), strict=False)
+    assert res.unexpected_keys == []
+    assert all(k.startswith("image_feature_encoder.") for k in res.missing_keys)
+    ref_sd, my_sd = ref.state_dict(), mine.state_dict()
+    head = [k for k in my_sd if not k.startswith("image_feature_encoder.")]
+    assert len(head) >= 34 and all(torch.equal(ref_sd[k], my_sd[k]) for k in head)
+
+    # the other direction: the stage-1 model's state dict holds the tokenizer under `tokenizer.` (and a detokenizer beside it)
+    theirs = {"tokenizer." + k: v.clone() for k, v in tok.state_dict().items() if not k.startswith("image_feature_encoder.")}
+    theirs["detokenizer.decoder_norm.weight"] = torch.ones(3)             # comes along through the keyword match, dropped by strict=False
+    res = C.load_pretrained_tokenizer(mine, theirs)
+    assert res.unexpected_keys == ["decoder_norm.weight"]
+    assert all(torch.equal(tok.state_dict()[k], mine.state_dict()[k]) for k in head)

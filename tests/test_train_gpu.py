@@ -244,3 +244,45 @@ def test_training_step_full_dims_deterministic_bf16():
             assert float(g1[n].abs().max()) > 0, n
     kb = g1["inner_encoder.layers.0.1.qkv.bias"][C:2 * C]
     assert float(kb.abs().max()) <= 1e-2 * float(g1["inner_encoder.layers.0.1.qkv.bias"].abs().max())
+
+
+def test_training_checkpoint_resume_is_bit_exact(tmp_path):
+    """Stop after 2 steps, save (`tokenizer.bin` under the reference's stage-1 key names + the optimiser state), load into a freshly
+    initialised tokenizer / trainer, continue: steps 3 and 4 equal the uninterrupted run bit for bit (weights, moments, outputs)."""
+    from setok_amd import checkpoint as Ck
+    C, N, B = 256, 64, 8
+    vc = dict(hidden_size=C, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, image_size=112, patch_size=14)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        t = SetokTokenizer(vision_tower=vc, mm_vision_select_layer=-2, hidden_dim=C, token_feat_dim=128, min_cluster_num=8,
+                           threshold=0.5, nheads=2, dim_feedforward=512).to(device=DEV, dtype=torch.bfloat16).eval()
+        return t, HeadTrainer(t, lr=2e-3, weight_decay=0.01)
+
+    g = torch.Generator().manual_seed(0)
+    hidden = torch.randn(B * (N + 1), C, generator=g).to(device=DEV, dtype=torch.bfloat16)
+
+    def step(tok, tr):
+        tokens, ctx = head_forward_train(tok, hidden, B)
+        diff = tokens.packed.float() - 0.5
+        tr.backward(ctx, (2.0 * diff / diff.numel()).to(torch.bfloat16))
+        tr.step()
+        return tokens.packed.clone()
+
+    tok_a, tr_a = make(0)
+    for _ in range(2):
+        step(tok_a, tr_a)
+    paths = Ck.save_training_checkpoint(tr_a, tmp_path / "checkpoint-2")
+    assert all(k.startswith("tokenizer.") for k in torch.load(paths["tokenizer"]))
+    tok_b, tr_b = make(123)                                              # different initial weights: everything must come from the files
+    Ck.load_training_checkpoint(tr_b, tmp_path / "checkpoint-2")
+    assert tr_b.t == 2 and tr_b.wd == 0.01
+    for _ in range(2):
+        out_a, out_b = step(tok_a, tr_a), step(tok_b, tr_b)
+        assert torch.equal(out_a, out_b)
+    for n in tr_a.master:
+        assert torch.equal(tr_a.master[n], tr_b.master[n]) and torch.equal(tr_a.m[n], tr_b.m[n]) and torch.equal(tr_a.v[n], tr_b.v[n]), n
+        assert torch.equal(tr_a.params[n], tr_b.params[n]), n
+    with pytest.raises(KeyError):
+        bad = Ck.trainer_state(tr_a); bad["exp_avg"].pop(next(iter(bad["exp_avg"])))
+        Ck.load_trainer_state(tr_b, bad)
