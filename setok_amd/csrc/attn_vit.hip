@@ -39,7 +39,15 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
                                                            int64_t ldkv, const int32_t* __restrict__ kv_offsets, int Tq_,
                                                            int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int h = blockIdx.x, b = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With 8 | images all heads of one image are put on ONE XCD
+    // (image b on XCD b % 8): a 48-dim head is 96 bytes of a q|k|v row, so neighbouring heads share 128-byte lines, and lines
+    // fetched by one XCD's L2 are not visible to another's.
+    int h = blockIdx.x, b = blockIdx.y;
+    if ((gridDim.y & 7) == 0 && DH != 64) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, k = id >> 3;
+        b = xcd + 8 * (k / (int)gridDim.x);
+        h = k % (int)gridDim.x;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = H * DH;
     int kv0 = 0;
