@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         }
 
         // One K-tile: 4 k-steps of {6 ds_read_b128, 8 MFMA}; with LOAD the 8 LDS-DMA loads of K-tile `k_next` (this tile's
-        // next one, or the next tile's first) go out two per k-step between the fragment reads and the MFMAs.
+        // next one, or the next tile's first) go out between the MFMAs of the first two k-steps.
         auto multiply = [&](auto load_tag, bool do_load, int k_next) {
             constexpr bool LOAD = decltype(load_tag)::value;
             const char* Ab = smem + (cnt & 1) * STAGE;
@@ -186,23 +186,26 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                     const int r = wm * WR + t * 32 + frow;
                     af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
                 }
-                if (LOAD && do_load) {
-                    // the whole next K-tile is requested in the first two k-steps (two A and two B pieces per thread each): the
-                    // requests then have two more k-steps to land before the vmcnt wait at the top of the next K-tile
-                    // (measured within one box, alternating: +1..2 % at K = 1024, +3..5 % at K = 4096 against one piece pair per k-step)
-                    if (ks < 2) {
-                        dma16(a_src[2 * ks] + k_next, sb + (2 * ks) * 8192);
-                        dma16(a_src[2 * ks + 1] + k_next, sb + (2 * ks + 1) * 8192);
-                        dma16(b_src[2 * ks] + k_next, sb + BOFF + (2 * ks) * 8192);
-                        dma16(b_src[2 * ks + 1] + k_next, sb + BOFF + (2 * ks + 1) * 8192);
-                    }
-                }
+                // The whole next K-tile is requested during the first two k-steps, ONE request after every second MFMA: requested early
+                // they have two more k-steps to land before the vmcnt wait at the top of the next K-tile (+1..5 % against one piece pair
+                // per k-step), and a vector-memory instruction holds its wave until the address unit has taken it (16 cycles per 1 KiB
+                // request, all eight waves asking), so four in a row stalled the MFMA stream behind them (spread out: +1..4 % on the ViT
+                // shapes, +5..8 % at 4096^3 / 8192^3, alternating runs on one box).
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    if (LOAD && ks < 2) {
+                        if (do_load) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (i < 2) dma16(a_src[2 * ks + i] + k_next, sb + (2 * ks + i) * 8192);
+                            else dma16(b_src[2 * ks + i - 2] + k_next, sb + BOFF + (2 * ks + i - 2) * 8192);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
             }
             ++cnt;
