@@ -20,7 +20,7 @@
 //     round and share operand panels.
 //   * a second kernel (256 x 64 tiles, 8 waves stacked along M, three 40 KiB stages) finishes the < 1-round remainder of M so
 //     that the big launch runs an exact number of rounds (no tail).
-// The chip is POWER-bound on this kernel (measured with rocm-smi under load: 1.37-1.38 kW of the 1.4 kW cap, sclk 1.95 GHz on
+// The chip is POWER-bound on this kernel (measured with rocm-smi under load: 1.37-1.38 kW of the 1.4 kW cap, sclk 1.73-1.95 GHz on
 // random operands vs 2.39 GHz / 0.95 kW on all-zero operands), so removing stall cycles converts only partly into speed: the
 // tile-boundary change above cut 9 % of the cycles per tile and 3 % of the time.
 #include "common.h"
