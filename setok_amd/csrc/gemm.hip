@@ -10,7 +10,10 @@
 //    swizzle (slot ^= row & 7) so a ds_read_b128 lane group is <= 2-way conflicted
 //    (cdna_hip_programming.md T2).
 //  * the big bf16 Linear layers (>= 96 output tiles of 256x256) go to the persistent direct-to-LDS kernel
-//    in gemm_persist.hip; the kernel below serves small problems, fp32 outputs (Gram matrix) and batches.
+//    in gemm_persist.hip, every smaller bf16 -> bf16 problem with N % 64 == 0 to that file's 64x64 eight-stage
+//    LDS-DMA kernel (a handful of images is latency-bound: 257 x 3072 x 1024 takes 9 us there against 36 us
+//    here; one-image encode 9.0 -> 3.8 ms); the kernel below serves fp32 outputs (Gram matrix), batches and
+//    odd N.  All three give the same bits for the same row (bias as accumulator init, ascending k).
 //  * fp32 kernel  (parity mode): 64x64x16 block tile, 4 waves, v_mfma_f32_32x32x2_f32 — bit-for-bit a
 //    k-ordered fmaf chain, so results do not depend on tile geometry.
 #include "common.h"
@@ -141,6 +144,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                             bf16* C, int64_t ldc, int M, int N, int K, int act);    // gemm_persist.hip
+int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
+                          bf16* C, int64_t ldc, int M, int N, int K, int act);      // gemm_persist.hip
 int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
                                    int64_t sA, int64_t sW, int64_t sC);               // gemm_persist.hip
 
@@ -248,6 +253,13 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
         if (out_dtype == SETOK_F32 && !bias && !residual && act == SETOK_ACT_NONE && N % 64 == 0 && K >= 192 && ldc % 4 == 0 &&
             strideA % 8 == 0 && strideW % 8 == 0 && strideC % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) * batch >= 96 && !g_force_small_tiles)
             return setok_gemm_persist_f32_batched(s, (const bf16*)A, lda, (const bf16*)W, (float*)C, ldc, M, N, K, batch, strideA, strideW, strideC);
+        // every other bf16 -> bf16 problem with N % 64 == 0: 64 x 64 tiles, eight-stage LDS-DMA pipeline (gemm_persist.hip).
+        // SETOK_GEMM_SMALL64_MAXTILES=<n> (test hook) limits it to problems of at most n 128 x 128 tiles.
+        {
+            static const int small_max = [] { const char* e = getenv("SETOK_GEMM_SMALL64_MAXTILES"); return e ? atoi(e) : 0x7fffffff; }();
+            if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && ldc % 8 == 0 && cdiv(M, BM) * cdiv(N, BN) <= small_max && !g_force_small_tiles)
+                return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
+        }
         dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
         if (out_dtype == SETOK_BF16) gemm_bf16_kernel<bf16, true><<<grid, 256, 0, s>>>(g);
         else if (out_dtype == SETOK_F32) gemm_bf16_kernel<float, false><<<grid, 256, 0, s>>>(g);

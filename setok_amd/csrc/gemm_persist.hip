@@ -532,6 +532,14 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     return launch_tail(s, t, act);
 }
 
+// Called by setok_linear for SMALL bf16 -> bf16 problems (a handful of images: too few 128 x 128 tiles to fill 256 CUs): the deep-pipelined
+// 64 x 64 kernel over the whole problem.
+int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
+                          bf16* C, int64_t ldc, int M, int N, int K, int act) {
+    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, TT), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1};
+    return launch_tail(s, t, act);
+}
+
 // Called by setok_linear for bf16 -> fp32 batched problems (no bias / activation / residual): the split-K partial products of a weight
 // gradient.  Same kernel, F32B variant.
 int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
