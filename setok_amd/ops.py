@@ -23,7 +23,15 @@ def _code(dt: torch.dtype) -> int:
     raise TypeError(f"setok_amd supports float32 and bfloat16, got {dt}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The HIP stream torch is currently recording on, as an integer handle.  (`torch.cuda.current_stream()` builds a Python Stream object
+    per call — 8 us, 1.5 ms of host time per encode at ~200 launches; the raw getter is 0.3 us.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
