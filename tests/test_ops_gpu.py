@@ -91,6 +91,20 @@ def test_linear_bf16_large_no_bias_and_alias():
     assert _rel_err(buf, ref.bfloat16().double() + r.double()) < 6e-3
 
 
+@pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (2, True), (0, True)])
+def test_linear_bf16_rows_do_not_depend_on_the_kernel(act, use_res):
+    """The same rows through the persistent 256 x 256 kernel (M = 25 k: 392 tiles), through its 64 x 64 tail / small-problem kernel
+    (M = 257, 63, 1) and inside a mid-size problem give the same bits: a sample alone equals the sample inside a batch."""
+    M, N, K = 25088, 1024, 1024
+    a, w = _rand(M, K, seed=11).bfloat16().to(DEV), (_rand(N, K, seed=12, scale=K ** -0.5)).bfloat16().to(DEV)
+    b = _rand(N, seed=13).to(DEV)
+    r = _rand(M, N, seed=14).bfloat16().to(DEV) if use_res else None
+    big = ops.linear(a, w, b, r, act=act)
+    for m in (1, 63, 257, 1028, 4112):
+        small = ops.linear(a[:m].contiguous(), w, b, None if r is None else r[:m].contiguous(), act=act)
+        assert torch.equal(small, big[:m]), m
+
+
 def test_linear_transpose_detecting():
     """A = I with an asymmetric W catches a swapped C/D fragment mapping (cdna guide rule 16)."""
     K = 128
