@@ -9,7 +9,7 @@
 //    staging, LDS double-buffered, one barrier per K tile.  LDS rows are 128 B with a 16-B-slot XOR
 //    swizzle (slot ^= row & 7) so a ds_read_b128 lane group is <= 2-way conflicted
 //    (cdna_hip_programming.md T2).
-//  * the big bf16 Linear layers (>= 96 output tiles of 256x256) go to the persistent direct-to-LDS kernel
+//  * the big bf16 Linear layers (>= 48 output tiles of 256x256) go to the persistent direct-to-LDS kernel
 //    in gemm_persist.hip, every smaller bf16 -> bf16 problem with N % 64 == 0 to that file's 64x64 eight-stage
 //    LDS-DMA kernel (a handful of images is latency-bound: 257 x 3072 x 1024 takes 9 us there against 36 us
 //    here; one-image encode 9.0 -> 3.8 ms); the kernel below serves fp32 outputs (Gram matrix), batches and
@@ -246,8 +246,9 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
     if (dtype == SETOK_BF16) {
         SETOK_CHECK_ARG(K % BK == 0, "setok_linear(bf16): K=%d must be a multiple of %d", K, BK);
         SETOK_CHECK_ARG(lda % 8 == 0, "setok_linear(bf16): lda must be a multiple of 8");
-        // big problems (>= 96 tiles of 256x256): persistent direct-to-LDS kernel (gemm_persist.hip)
-        if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 96 && !g_force_small_tiles)
+        // big problems (>= 48 tiles of 256x256; measured crossover against the 64x64 kernel: ~50 tiles): persistent direct-to-LDS kernel (gemm_persist.hip)
+        static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();   // test hook
+        if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= persist_min && !g_force_small_tiles)
             return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
         // fp32-out batched problems without bias / activation / residual and with enough tiles (weight-gradient partial products)
         if (out_dtype == SETOK_F32 && !bias && !residual && act == SETOK_ACT_NONE && N % 64 == 0 && K >= 192 && ldc % 4 == 0 &&

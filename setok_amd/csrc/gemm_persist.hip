@@ -491,7 +491,7 @@ int cu_count() {
 
 }  // namespace
 
-// Called by setok_linear (gemm.hip) for bf16 -> bf16 problems with >= 96 tiles of 256x256.
+// Called by setok_linear (gemm.hip) for bf16 -> bf16 problems with >= 48 tiles of 256x256.
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                             bf16* C, int64_t ldc, int M, int N, int K, int act) {
     const int ncu = cu_count();

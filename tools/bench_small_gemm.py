@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from setok_amd import ops
-for M in (257, 1028, 2056, 4112, 6168):
+for M in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (257, 1028, 2056, 4112, 6168)):
     for name, N, K in (("qkv", 3072, 1024), ("proj", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096), ("out", 4096, 1024), ("dec", 768, 768), ("llm", 4096, 4096)):
         a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
         b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
