@@ -501,7 +501,17 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     int p = 0;
     const int T = tilesM * tilesN, r = T % ncu;
     if (T > ncu && r != 0 && r % tilesN == 0 && r / tilesN <= 2) p = r / tilesN;
-    static const int dbg = [] { const char* e = getenv("SETOK_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+    // SETOK_GEMM_DEBUG: bit 2 = no M-tail peel, bit 3 = everything through the 64x64 kernel (both leave the results unchanged).  Bits 0 / 1
+    // (skip the C stores / the residual: ablation runs for the cycle breakdown in DESIGN.md) change the results and exist only in builds
+    // with -DSETOK_GEMM_ABLATION.
+    static const int dbg = [] {
+        const char* e = getenv("SETOK_GEMM_DEBUG");
+        int v = e ? atoi(e) : 0;
+#ifndef SETOK_GEMM_ABLATION
+        v &= ~3;
+#endif
+        return v;
+    }();
     if (dbg & 4) p = 0;
     if (dbg & 8) p = tilesM;                                        // experiment: everything through the deep-pipeline 64x64 kernel
     const int tm_main = tilesM - p;
