@@ -31,8 +31,9 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0              # HBM3E, MI355X_MICROARCH.md
-MFMA_ONLY_RANDOM_TFLOPS = 1847.0   # measured: tools/micro/mfma_peak.hip (register-resident MFMA loop, random bf16 operands, power-managed
-                                   # to 1.95 GHz / 1.28 kW; 2449 TFLOP/s at 2.40 GHz on all-zero operands) — profiles/r01_mfma_peak.log
+MFMA_ONLY_RANDOM_TFLOPS = 2080.0   # measured: tools/micro/mfma_peak.hip (register-resident loop of v_mfma_f32_16x16x32_bf16 — the shape the GEMM
+                                   # kernels use — on random bf16 operands, power-managed to 2.11 GHz / 1.37 kW; 2455 TFLOP/s at 2.40 GHz on
+                                   # all-zero operands; the 32x32x16 shape: 1855) — profiles/r01_mfma_peak.log
 B_PER_GPU, IMG, PATCH = 256, 224, 14
 THRESHOLD, KNN = 0.125, 64         # dyn-k fires with seeded random-init features
 

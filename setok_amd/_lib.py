@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsetok_hip.so")
+LIB_PATH = os.environ.get("SETOK_HIP_LIB") or os.path.join(_HERE, "libsetok_hip.so")   # SETOK_HIP_LIB: another build of the same ABI (A/B runs)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2

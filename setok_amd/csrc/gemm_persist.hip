@@ -48,11 +48,15 @@ __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retire
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// 16-byte-slot swizzle of a 128-byte LDS row: a ds_read_b128 is served in four 16-lane groups
-// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32), one 256-byte bank row per cycle.  A group reads 16 rows of one
-// 32-row MFMA tile at one logical slot; with slot ^= swz(row) its 16 accesses fall on 16 different physical
-// (row parity, slot) positions of the bank row -> conflict-free (row & 7 would be 2-way).
-__device__ inline int swz(int row) { return ((row >> 1) & 1) | (((row >> 4) & 1) << 1) | (((row >> 3) & 1) << 2); }
+// MFMA shape: v_mfma_f32_16x16x32_bf16.  A register-resident loop of it sustains 2080 TFLOP/s on random bf16 operands under the socket's
+// power management against 1855 for v_mfma_f32_32x32x16_bf16 (759 W vs 879 W on all-zero operands at the same 2456 TFLOP/s: half the
+// accumulator traffic per FLOP) — tools/micro/mfma_peak.hip, profiles/r01_mfma_peak.log; and this GEMM is power-bound.
+// Fragment of a 16-row tile: lane l reads row (l & 15), 16-byte slot ks * 4 + (l >> 4) of the 128-byte LDS row (8 consecutive k).
+// 16-byte-slot swizzle: a ds_read_b128 is served in four 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32), one 256-byte bank
+// row per cycle.  A group reads the 16 rows of a tile, 8 of them at slot c and 8 at slot c + 1; with slot ^= (row >> 1) & 7 the eight
+// rows of either parity fall on eight different slots for every c -> conflict-free.
+__device__ inline int swz(int row) { return (row >> 1) & 7; }
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <int N_>
 __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
@@ -76,7 +80,8 @@ __device__ float kZeroBias[64];                    // stands in for a null bias 
 // dW = dY^T X (training.py), which by themselves have too few output tiles to fill the chip.
 template <int ACT, bool F32B>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
-    constexpr int WNC = 4, WR = 128, MI = 4, TNB = 256;
+    constexpr int WNC = 4, WR = 128, MI = 4, TNB = 256;   // MI: 32-row epilogue passes per wave
+    constexpr int MT = 8, NT = 4;                           // 16 x 16 MFMA tiles per wave: 8 along M (128 rows) x 4 along N (64 columns)
     constexpr int NL = 8;                          // LDS-DMA ops per lane per K-tile
     constexpr int NSTORE = WR / 8;                 // 16-byte stores per lane per (interior) tile
 
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNC, wn = wave % WNC;
-    const int frow = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
     const int tiles_per_problem = g.tilesM * g.tilesN;
     const int num_tiles = tiles_per_problem * (F32B ? g.nbatch : 1);
@@ -148,65 +153,67 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 
         // ---- accumulators start at the bias (fp32, added before the single bf16 rounding): scalar loads.  N % 64 == 0
         //      (dispatch condition), so a wave's 64 columns are all inside or all outside the matrix ---------------------
-        f32x16 acc[MI][2];
+        f32x4 acc[MT][NT];
         {
             const int cb = g.bias ? min(n0 + wn * 64, g.N - 64) : 0;       // wave-uniform first column
             const __attribute__((address_space(4))) float* bp =
                 (const __attribute__((address_space(4))) float*)(unsigned long long)(g.bias ? g.bias + cb : g.zero_bias);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
+                for (int e = 0; e < 4; ++e) {                              // this lane's columns of tile j: j * 16 + 4 * g4 + e
+                    const float b0 = bp[j * 16 + e], b1 = bp[j * 16 + 4 + e], b2 = bp[j * 16 + 8 + e], b3 = bp[j * 16 + 12 + e];
+                    const float b = g4 == 0 ? b0 : g4 == 1 ? b1 : g4 == 2 ? b2 : b3;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = bp[j * 32 + q4 * 8 + e], up = bp[j * 32 + q4 * 8 + 4 + e];
-                        const float b = hi ? up : lo;
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) acc[i][j][q4 * 4 + e] = b;
-                    }
+                    for (int t = 0; t < MT; ++t) acc[t][j][e] = b;
+                }
         }
 
-        // One K-tile: 4 k-steps of {6 ds_read_b128, 8 MFMA}; with LOAD the 8 LDS-DMA loads of K-tile `k_next` (this tile's
-        // next one, or the next tile's first) go out between the MFMAs of the first two k-steps.
+        // One K-tile: 2 k-steps of {12 ds_read_b128, 32 MFMA 16x16x32}; with LOAD the 8 LDS-DMA loads of K-tile `k_next` (this tile's
+        // next one, or the next tile's first) go out between the MFMAs of the first k-step.
         auto multiply = [&](auto load_tag, bool do_load, int k_next) {
             constexpr bool LOAD = decltype(load_tag)::value;
             const char* Ab = smem + (cnt & 1) * STAGE;
             const char* Bb = Ab + BOFF;
             const unsigned sb = lds0 + ((cnt + 1) & 1) * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 wf[2], af[MI];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 wf[NT];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int r = wn * 64 + t * 32 + frow;
-                    wf[t] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
+                for (int t = 0; t < NT; ++t) {
+                    const int r = wn * 64 + t * 16 + l15;
+                    wf[t] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
                 }
+                // The whole next K-tile is requested during the first half of this one, ONE request after every fourth MFMA (64 cycles):
+                // requested early they have the second half to land before the vmcnt wait at the top of the next K-tile (+1..5 % against
+                // requests spread over the whole K-tile), and a vector-memory instruction holds its wave until the address unit has taken
+                // it (16 cycles per 1 KiB request, all eight waves asking), so several in a row stalled the MFMA stream behind them
+                // (spread out: +1..4 % on the ViT shapes, +5..8 % at 4096^3 / 8192^3, alternating runs on one box).
 #pragma unroll
-                for (int t = 0; t < MI; ++t) {
-                    const int r = wm * WR + t * 32 + frow;
-                    af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 2 + hi) ^ swz(r)) << 4));
-                }
-                // The whole next K-tile is requested during the first two k-steps, ONE request after every second MFMA: requested early
-                // they have two more k-steps to land before the vmcnt wait at the top of the next K-tile (+1..5 % against one piece pair
-                // per k-step), and a vector-memory instruction holds its wave until the address unit has taken it (16 cycles per 1 KiB
-                // request, all eight waves asking), so four in a row stalled the MFMA stream behind them (spread out: +1..4 % on the ViT
-                // shapes, +5..8 % at 4096^3 / 8192^3, alternating runs on one box).
-                __builtin_amdgcn_s_setprio(1);
+                for (int half = 0; half < 2; ++half) {                     // the activation fragments in two batches of four (register budget)
+                    bf16x8 af[4];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = wm * WR + (half * 4 + t) * 16 + l15;
+                        af[t] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
+                    }
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                    if (LOAD && ks < 2) {
-                        if (do_load) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (i < 2) dma16(a_src[2 * ks + i] + k_next, sb + (2 * ks + i) * 8192);
-                            else dma16(b_src[2 * ks + i - 2] + k_next, sb + BOFF + (2 * ks + i - 2) * 8192);
-                            __builtin_amdgcn_sched_barrier(0);
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[half * 4 + t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[t], acc[half * 4 + t][j], 0, 0, 0);
+                        if (LOAD && ks == 0) {
+                            if (do_load) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (half == 0) dma16(a_src[t] + k_next, sb + t * 8192);
+                                else dma16(b_src[t] + k_next, sb + BOFF + t * 8192);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
-                __builtin_amdgcn_s_setprio(0);
             }
             ++cnt;
         };
@@ -237,7 +244,12 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         //      in here asks for a store to have completed.
         const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N) && !(g.dbg & 1);
         const bool use_res = g.res && !(g.dbg & 2);
-        const int slot = lane & 7;
+        // The lane-only parts of the store / residual addresses are recomputed per tile from an opaque copy of the lane id: hoisted out of
+        // the tile loop they are ~30 registers that live across the main loop, get spilled, and come back one scratch load per store
+        // (epilogue 6 k -> 15 k cycles per tile).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int slot = lane_e & 7, lrow = lane_e >> 3;
         const int col = n0 + wn * 64 + slot * 8;
         const bool col_ok = col < g.N;
         char* stg = smem + 2 * STAGE + wave * 4096;
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         auto load_residual = [&](auto int_tag, int h) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int grow = m0 + wm * WR + h * 32 + it * 8 + (lane >> 3);
+                const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
                 if (decltype(int_tag)::value || (grow < g.M && col_ok))
                     rv[h & 1][it] = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
             }
@@ -263,24 +275,26 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
             for (int h = 0; h < MI; ++h) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int tt = 0; tt < 2; ++tt)                            // the two 16-row MFMA tiles of this 32-row pass
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
+                    for (int j = 0; j < NT; ++j) {
                         bf16x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float x = acc[h][j][q4 * 4 + e];
+                            float x = acc[2 * h + tt][j][e];
                             if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
                             else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
                             v[e] = (bf16)x;
                         }
-                        *reinterpret_cast<bf16x4*>(stg + frow * 128 + (((j * 4 + q4) ^ (frow & 7)) << 4) + 8 * hi) = v;
+                        // row tt * 16 + l15 of the pass, columns j * 16 + 4 * g4 .. + 3: 16-byte slot j * 2 + (g4 >> 1), its half g4 & 1
+                        const int srow = tt * 16 + l15;
+                        *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((j * 2 + (g4 >> 1)) ^ (srow & 7)) << 4) + 8 * (g4 & 1)) = v;
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // a wave re-reads only its own staging rows
                 bf16x8 ov[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const int row = it * 8 + (lane >> 3);
+                    const int row = it * 8 + lrow;
                     ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
                 }
                 if (RES) {
@@ -296,31 +310,29 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                 if (RES && h + 1 < MI) load_residual(int_tag, h + 1);     // requested before this pass's stores (vmcnt retires in order)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const int grow = m0 + wm * WR + h * 32 + it * 8 + (lane >> 3);
+                    const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
                     if (INT || (grow < g.M && col_ok && !(g.dbg & 1)))
                         *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = ov[it];
                 }
             }
         };
         if constexpr (F32B) {
-            // fp32 out: a lane holds, for output row frow of each 32-row tile, 4 consecutive columns per accumulator quad -> 16-byte stores
+            // fp32 out: a lane holds, for output row l15 of each 16-row tile, 4 consecutive columns per accumulator -> 16-byte stores
             if (has_next) issue_ktile((cnt + 1) & 1, TK);
             float* Cb = g.Cf + (int64_t)bz * g.sC;
 #pragma unroll
-            for (int h = 0; h < MI; ++h) {
-                const int grow = m0 + wm * WR + h * 32 + frow;
+            for (int t = 0; t < MT; ++t) {
+                const int grow = m0 + wm * WR + t * 16 + l15;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NT; ++j) {
+                    const int c = n0 + wn * 64 + j * 16 + 4 * g4;
+                    if (grow < g.M && c < g.N) {
+                        f32x4 v;
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int c = n0 + wn * 64 + j * 32 + q4 * 8 + 4 * hi;
-                        if (grow < g.M && c < g.N) {
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[h][j][q4 * 4 + e];
-                            *reinterpret_cast<f32x4*>(Cb + (int64_t)grow * g.ldc + c) = v;
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = acc[t][j][e];
+                        *reinterpret_cast<f32x4*>(Cb + (int64_t)grow * g.ldc + c) = v;
                     }
+                }
             }
         } else {
             if (use_res) { if (interior) epilogue(yes{}, yes{}); else epilogue(yes{}, no{}); }
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int frow = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
     const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TT;
     float* sbias = reinterpret_cast<float*>(smem + TNS * TSTAGE);
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     };
     for (int kt = 0; kt < TNS - 1 && kt < nk; ++kt) issue(kt);
 
-    f32x16 acc;
+    f32x4 acc[2][2];                                        // this wave's 32 x 32: 2 x 2 MFMA tiles of 16 x 16
     for (int kt = 0; kt < nk; ++kt) {
         // K-tile kt has landed for this wave: at most the 4 * min(6, nk - 1 - kt) younger loads may still fly
         switch (min(TNS - 2, nk - 1 - kt)) {
@@ -398,34 +410,48 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
         if (kt + TNS - 1 < nk) issue(kt + TNS - 1);         // ... which is the stage K-tile kt + 7 goes to
         if (kt == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = sbias[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b = sbias[wn * 32 + j * 16 + 4 * g4 + e];
+                    acc[0][j][e] = b; acc[1][j][e] = b;
+                }
         }
         const char* Ab = smem + (kt % TNS) * TSTAGE;
         const char* Bb = Ab + TT * TK * 2;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int rb = wn * 32 + frow, ra = wm * 32 + frow;
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 2 + hi) ^ swz(rb)) << 4));
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 2 + hi) ^ swz(ra)) << 4));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[2], af[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rb = wn * 32 + t * 16 + l15, ra = wm * 32 + t * 16 + l15;
+                wf[t] = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 4 + g4) ^ swz(rb)) << 4));
+                af[t] = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 4 + g4) ^ swz(ra)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[t], acc[t][j], 0, 0, 0);
         }
     }
     // epilogue: the 64 x 64 tile is transposed through stage 0 (every load has landed; the barrier orders the last reads)
     s_barrier_lgkm();
     char* stg = smem;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-        bf16x4 v;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = acc[q4 * 4 + e];
-            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
-            else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-            v[e] = (bf16)x;
+        for (int j = 0; j < 2; ++j) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[t][j][e];
+                if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
+                else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                v[e] = (bf16)x;
+            }
+            const int row = wm * 32 + t * 16 + l15;                 // columns wn * 32 + j * 16 + 4 * g4 .. + 3
+            *reinterpret_cast<bf16x4*>(stg + row * 128 + (((wn * 4 + j * 2 + (g4 >> 1)) ^ (row & 7)) << 4) + 8 * (g4 & 1)) = v;
         }
-        const int row = wm * 32 + frow;
-        *reinterpret_cast<bf16x4*>(stg + row * 128 + (((wn * 4 + q4) ^ (row & 7)) << 4) + 8 * hi) = v;
-    }
     s_barrier_lgkm();
     const int slot = tid & 7, col = n0 + slot * 8;
 #pragma unroll
