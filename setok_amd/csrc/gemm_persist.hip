@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 // Tail kernel: the < 1-round remainder of M (p*256 rows; the ViT's 257 tokens per image leave one 256-row slab after every
 // exact number of rounds).  A handful of tiles cannot fill 256 CUs, so this launch is pure latency: with 256 x 64 tiles and three
 // stages it took 24 us (16 K-tiles at 1.5 us each) for 0.4 % of the GEMM's work — 7 % of its time.  Hence small tiles and a deep
-// pipeline: 64 x 64 tiles (4 waves, one 32 x 32 MFMA tile each), EIGHT 16 KiB stages, seven K-tiles of operands in flight, every
+// pipeline: 64 x 64 tiles (4 waves, 32 x 32 = 2 x 2 MFMA tiles of 16 x 16 each), EIGHT 16 KiB stages, seven K-tiles of operands in flight, every
 // wait counted.  Same arithmetic per output element as the main kernel (bias as accumulator init, ascending k, one bf16 rounding,
 // round-then-add residual): a row's result does not depend on which kernel produced it.
 // --------------------------------------------------------------------------------------------
