@@ -78,7 +78,8 @@ __device__ float kZeroBias[64];                    // stands in for a null bias 
 // F32B = false: the bf16-out kernel of every large Linear.  F32B = true: fp32 output written straight from the accumulators (the outputs
 // are weight-gradient sized, store efficiency is irrelevant) for a BATCH of problems sharing M, N, K — the split-K partial products of
 // dW = dY^T X (training.py), which by themselves have too few output tiles to fill the chip.
-template <int ACT, bool F32B>
+// RESK: the launch has a residual (its own instantiation: the residual rows' registers and code do not burden the kernels without one).
+template <int ACT, bool F32B, bool RESK = false>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     constexpr int WNC = 4, WR = 128, MI = 4, TNB = 256;   // MI: 32-row epilogue passes per wave
     constexpr int MT = 8, NT = 4;                           // 16 x 16 MFMA tiles per wave: 8 along M (128 rows) x 4 along N (64 columns)
@@ -112,29 +113,39 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         return true;
     };
 
-    const bf16* a_src[4]; const bf16* b_src[4];
+    // LDS-DMA source addresses: a wave-uniform 64-bit base (SGPR pair: the tile's first row, advanced by the K offset with scalar adds)
+    // + a 32-bit byte offset per lane and piece (row inside the tile, clamped at the matrix edge, and the swizzled 16-byte slot): half
+    // the address registers of 64-bit per-lane pointers for the address unit to read (qkv / fc1 +4 % sustained), 8 VGPRs less.
+    unsigned a_off[4], b_off[4];
+    const char* a_base; const char* b_base;
     auto set_src = [&](int m0, int n0, int b) {
         const bf16* Ab_ = F32B ? g.A + (int64_t)b * g.sA : g.A;
         const bf16* Wb_ = F32B ? g.W + (int64_t)b * g.sW : g.W;
+        a_base = reinterpret_cast<const char*>(Ab_ + (int64_t)m0 * g.lda);
+        b_base = reinterpret_cast<const char*>(Wb_ + (int64_t)n0 * g.K);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
-            a_src[i] = Ab_ + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-            b_src[i] = Wb_ + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
+            a_off[i] = (unsigned)min(row, g.M - 1 - m0) * (unsigned)(g.lda * 2) + kc * 16;       // < 256 rows x lda x 2 bytes
+            b_off[i] = (unsigned)min(row, g.N - 1 - n0) * (unsigned)(g.K * 2) + kc * 16;
         }
     };
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
-    auto dma16 = [&](const bf16* ptr, unsigned lds_dst) {
+    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(ptr), "s"(lds_dst) : "memory");
+        const unsigned long long b64 = (unsigned long long)base;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);          // (readfirstlane returns int: widen as unsigned)
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
     };
     auto issue_ktile = [&](int stage, int k0) {                      // a whole K-tile at once (tile boundaries only)
         const unsigned sb = lds0 + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(a_src[i] + k0, sb + i * 8192);
+        for (int i = 0; i < 4; ++i) dma16(a_base + k0 * 2, a_off[i], sb + i * 8192);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(b_src[i] + k0, sb + BOFF + i * 8192);
+        for (int i = 0; i < 4; ++i) dma16(b_base + k0 * 2, b_off[i], sb + BOFF + i * 8192);
     };
 
     int m0, n0, round = 0;
@@ -206,8 +217,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                         if (LOAD && ks == 0) {
                             if (do_load) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (half == 0) dma16(a_src[t] + k_next, sb + t * 8192);
-                                else dma16(b_src[t] + k_next, sb + BOFF + t * 8192);
+                                if (half == 0) dma16(a_base + k_next * 2, a_off[t], sb + t * 8192);
+                                else dma16(b_base + k_next * 2, b_off[t], sb + BOFF + t * 8192);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         //      so the next tile waits vmcnt(NSTORE + 8) for its first K-tile and vmcnt(NSTORE) for its second, and no wait
         //      in here asks for a store to have completed.
         const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N) && !(g.dbg & 1);
-        const bool use_res = g.res && !(g.dbg & 2);
+        constexpr bool use_res = RESK;
         // The lane-only parts of the store / residual addresses are recomputed per tile from an opaque copy of the lane id: hoisted out of
         // the tile loop they are ~30 registers that live across the main loop, get spilled, and come back one scratch load per store
         // (epilogue 6 k -> 15 k cycles per tile).
@@ -490,17 +501,20 @@ int launch_tail(hipStream_t s, const PArgs& g, int act) {
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
     static bool attr_set = false;
     if (!attr_set) {
-        bool ok = hipFuncSetAttribute((const void*)gemm_persist_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_persist_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+        bool ok = true;
+        const void* fns[] = {(const void*)gemm_persist_kernel<0, false, false>, (const void*)gemm_persist_kernel<1, false, false>,
+                             (const void*)gemm_persist_kernel<2, false, false>, (const void*)gemm_persist_kernel<0, false, true>,
+                             (const void*)gemm_persist_kernel<1, false, true>, (const void*)gemm_persist_kernel<2, false, true>};
+        for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
         if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
-    if (act == SETOK_ACT_NONE) gemm_persist_kernel<0, false><<<grid, 512, MAIN_LDS, s>>>(g);
-    else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1, false><<<grid, 512, MAIN_LDS, s>>>(g);
-    else gemm_persist_kernel<2, false><<<grid, 512, MAIN_LDS, s>>>(g);
+    const bool res = g.res && !(g.dbg & 2);
+    if (act == SETOK_ACT_NONE) { if (res) gemm_persist_kernel<0, false, true><<<grid, 512, MAIN_LDS, s>>>(g); else gemm_persist_kernel<0, false, false><<<grid, 512, MAIN_LDS, s>>>(g); }
+    else if (act == SETOK_ACT_QUICK_GELU) { if (res) gemm_persist_kernel<1, false, true><<<grid, 512, MAIN_LDS, s>>>(g); else gemm_persist_kernel<1, false, false><<<grid, 512, MAIN_LDS, s>>>(g); }
+    else { if (res) gemm_persist_kernel<2, false, true><<<grid, 512, MAIN_LDS, s>>>(g); else gemm_persist_kernel<2, false, false><<<grid, 512, MAIN_LDS, s>>>(g); }
     SETOK_CHECK_LAUNCH("setok_linear(persistent)");
     return SETOK_OK;
 }
