@@ -264,13 +264,20 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         const int col = n0 + wn * 64 + slot * 8;
         const bool col_ok = col < g.N;
         char* stg = smem + 2 * STAGE + wave * 4096;
+        // C / residual addresses = wave-uniform base of the wave's 128 x 64 block + uniform (h, it) row offset + ONE 32-bit lane offset: the
+        // 16 stores and 16 residual loads of a tile share a single offset register and go out in SGPR-base form.
+        const int64_t wave_elem = (int64_t)(m0 + wm * WR) * g.ldc + (n0 + wn * 64);
+        char* c_wave = reinterpret_cast<char*>(g.C + wave_elem);
+        const char* r_wave = reinterpret_cast<const char*>(g.res + (RESK ? wave_elem : 0));
+        const unsigned lane_off = (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
+        const unsigned row8 = (unsigned)g.ldc * 16u;                          // bytes between consecutive `it` (8 rows)
         bf16x8 rv[2][4];
         auto load_residual = [&](auto int_tag, int h) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
                 if (decltype(int_tag)::value || (grow < g.M && col_ok))
-                    rv[h & 1][it] = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
+                    rv[h & 1][it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
             }
         };
         s_barrier_lgkm();
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                 for (int it = 0; it < 4; ++it) {
                     const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
                     if (INT || (grow < g.M && col_ok && !(g.dbg & 1)))
-                        *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = ov[it];
+                        *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];
                 }
             }
         };
