@@ -38,6 +38,53 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
     }
 }
 
+// Rows of C = NCH * 64 * VEC elements (ViT-L: 1024 bf16 = 2 chunks per lane): the row stays in registers between the three passes, and a
+// wave keeps ITS columns of gamma / beta in registers across the rows it walks (read per row they are 4x the row's own bytes through L1).
+// Same arithmetic and summation order as the generic kernel above (results are bit-identical).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* y, int rows, float eps) {
+    constexpr int V = Elem<T>::VEC, C = NCH * 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float g[NCH][V], b[NCH][V];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) { g[k][i] = gamma[(k * 64 + lane) * V + i]; b[k][i] = beta[(k * 64 + lane) * V + i]; }
+    for (int row = wave0; row < rows; row += nwaves) {
+        const T* xr = x + (int64_t)row * C;
+        T* yr = y + (int64_t)row * C;
+        float buf[NCH][V];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) ld_vec<T>(xr + (k * 64 + lane) * V, buf[k]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) s += buf[k][i];
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { const float d = buf[k][i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) buf[k][i] = (buf[k][i] - mean) * rstd * g[k][i] + b[k][i];
+            st_vec<T>(yr + (k * 64 + lane) * V, buf[k]);
+        }
+    }
+}
+
+template <typename T, int NCH>
+static void launch_ln_rows(hipStream_t s, const void* x, const float* gamma, const float* beta, void* y, int rows, float eps) {
+    const int grid = min(cdiv(rows, 4), 256 * 8);
+    layernorm_rows_kernel<T, NCH><<<grid, 256, 0, s>>>((const T*)x, gamma, beta, (T*)y, rows, eps);
+}
+
 extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const float* gamma, const float* beta,
                                void* y, int rows, int C, float eps) {
     SETOK_CHECK_ARG(x && y && gamma && beta, "setok_layernorm: null operand");
@@ -45,6 +92,14 @@ extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const flo
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(rows, 4));
+    if (dtype == SETOK_BF16 && (C == 512 || C == 1024 || C == 1536 || C == 2048) && rows >= 1024) {
+        if (C == 512) launch_ln_rows<bf16, 1>(s, x, gamma, beta, y, rows, eps);
+        else if (C == 1024) launch_ln_rows<bf16, 2>(s, x, gamma, beta, y, rows, eps);
+        else if (C == 1536) launch_ln_rows<bf16, 3>(s, x, gamma, beta, y, rows, eps);
+        else launch_ln_rows<bf16, 4>(s, x, gamma, beta, y, rows, eps);
+        SETOK_CHECK_LAUNCH("setok_layernorm");
+        return SETOK_OK;
+    }
     if (dtype == SETOK_BF16) layernorm_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, gamma, beta, (bf16*)y, rows, C, eps);
     else if (dtype == SETOK_F32) layernorm_kernel<float><<<grid, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, eps);
     else return setok_fail(SETOK_EINVAL, "setok_layernorm: bad dtype %d", dtype);
