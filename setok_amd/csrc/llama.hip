@@ -36,6 +36,37 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
     }
 }
 
+// Rows of NCH * 64 * VEC elements (Llama hidden 4096 bf16 = 8 chunks per lane): the row stays in registers between the two passes and a wave
+// keeps its columns of the weight (already rounded to the activation dtype) across the rows it walks.  Same arithmetic and summation order.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int rows, float eps) {
+    constexpr int V = Elem<T>::VEC, C = NCH * 64 * V;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float wr[NCH][V];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) wr[k][i] = rnd<T>(w[(k * 64 + lane) * V + i]);
+    for (int row = wave0; row < rows; row += nwaves) {
+        const T* xr = x + (int64_t)row * C;
+        float buf[NCH][V], s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) ld_vec<T>(xr + (k * 64 + lane) * V, buf[k]);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) s += buf[k][i] * buf[k][i];
+        const float rstd = rsqrtf(wave_sum(s) / (float)C + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) buf[k][i] = wr[k][i] * rnd<T>(buf[k][i] * rstd);
+            st_vec<T>(y + (int64_t)row * C + (k * 64 + lane) * V, buf[k]);
+        }
+    }
+}
+
 // ---- rotary embedding on q and k of [q | k | v] rows -----------------------------------------------------------------------------------------
 // One thread per (row, chunk of V dims of the first half): cos / sin of its V angles are computed ONCE and reused for the row's 2H heads
 // (the angle depends on the position and the dim only), every head costs two 16-byte loads and two 16-byte stores.
@@ -286,6 +317,14 @@ extern "C" int setok_rmsnorm(void* stream, int dtype, const void* x, const float
     SETOK_CHECK_ARG(rows >= 0 && C > 0 && C % 8 == 0, "setok_rmsnorm: C=%d must be a positive multiple of 8", C);
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16 && (C == 4096 || C == 5120 || C == 2048) && rows >= 1024) {
+        const int grid = min(cdiv(rows, 4), 256 * 8);
+        if (C == 4096) rmsnorm_rows_kernel<bf16, 8><<<grid, 256, 0, s>>>((const bf16*)x, weight, (bf16*)y, rows, eps);
+        else if (C == 5120) rmsnorm_rows_kernel<bf16, 10><<<grid, 256, 0, s>>>((const bf16*)x, weight, (bf16*)y, rows, eps);
+        else rmsnorm_rows_kernel<bf16, 4><<<grid, 256, 0, s>>>((const bf16*)x, weight, (bf16*)y, rows, eps);
+        SETOK_CHECK_LAUNCH("setok_rmsnorm");
+        return SETOK_OK;
+    }
     LL_DISPATCH("setok_rmsnorm", (rmsnorm_kernel<bf16><<<cdiv(rows, 4), 256, 0, s>>>((const bf16*)x, weight, (bf16*)y, rows, C, eps)),
                 (rmsnorm_kernel<float><<<cdiv(rows, 4), 256, 0, s>>>((const float*)x, weight, (float*)y, rows, C, eps)));
     SETOK_CHECK_LAUNCH("setok_rmsnorm");
