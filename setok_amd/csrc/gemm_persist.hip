@@ -148,9 +148,24 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         for (int i = 0; i < 4; ++i) dma16(b_base + k0 * 2, b_off[i], sb + BOFF + i * 8192);
     };
 
+    // The bias of a tile is fetched ONE TILE AHEAD (4 floats per lane: columns j * 16 + (lane & 15) of the wave's 64), before the previous
+    // tile's last K-tile — i.e. ahead of that tile's store burst.  Read at the top of the tile (scalar loads then) it cost ~4 k cycles per
+    // tile: the request sat behind the stores of all 256 CUs.  The accumulators then start at the bias through 32 MFMAs on a fragment that
+    // holds the bias split into three bf16 parts (hi + mid + lo = the fp32 value exactly) against a fragment of ones: acc = 0 + hi + mid + lo
+    // is exact, so the arithmetic (bias first, then the products in ascending k) is unchanged bit for bit.
+    float nb[NT];
+    auto load_bias = [&](int n0_) {
+        if constexpr (!F32B) {
+            const float* bp = g.bias ? g.bias + min(n0_ + wn * 64, g.N - 64) : g.zero_bias;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) nb[j] = bp[j * 16 + l15];
+        }
+    };
+
     int m0, n0, round = 0;
     if (!tile_of(0, m0, n0, bz)) return;
     set_src(m0, n0, bz);
+    load_bias(n0);
     issue_ktile(0, 0);
     issue_ktile(1, TK);
     int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
@@ -162,23 +177,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         int nm0 = 0, nn0 = 0;
         const bool has_next = tile_of(round + 1, nm0, nn0, nbz);
 
-        // ---- accumulators start at the bias (fp32, added before the single bf16 rounding): scalar loads.  N % 64 == 0
-        //      (dispatch condition), so a wave's 64 columns are all inside or all outside the matrix ---------------------
         f32x4 acc[MT][NT];
-        {
-            const int cb = g.bias ? min(n0 + wn * 64, g.N - 64) : 0;       // wave-uniform first column
-            const __attribute__((address_space(4))) float* bp =
-                (const __attribute__((address_space(4))) float*)(unsigned long long)(g.bias ? g.bias + cb : g.zero_bias);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {                              // this lane's columns of tile j: j * 16 + 4 * g4 + e
-                    const float b0 = bp[j * 16 + e], b1 = bp[j * 16 + 4 + e], b2 = bp[j * 16 + 8 + e], b3 = bp[j * 16 + 12 + e];
-                    const float b = g4 == 0 ? b0 : g4 == 1 ? b1 : g4 == 2 ? b2 : b3;
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t][j][e] = b;
-                }
-        }
 
         // One K-tile: 2 k-steps of {12 ds_read_b128, 32 MFMA 16x16x32}; with LOAD the 8 LDS-DMA loads of K-tile `k_next` (this tile's
         // next one, or the next tile's first) go out between the MFMAs of the first k-step.
@@ -237,6 +236,36 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
         }
         s_barrier_lgkm();
+        {   // ---- accumulators start at the bias (fp32, added before the single bf16 rounding) -------------------------------------------
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 bw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bw[e] = (bf16)0.0f;
+                if constexpr (!F32B) {
+                    // three-way exact split by truncation (top 16 bits of the fp32 pattern each time); only the k-group-0 lanes carry it
+                    const float b = nb[j];
+                    const float hi1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffff0000u);
+                    const float r1 = b - hi1;
+                    const float hi2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+                    const float r2 = r1 - hi2;
+                    const bool fin = __builtin_isfinite(b);
+                    if (g4 == 0) {
+                        bw[0] = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, b) >> 16));
+                        bw[1] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r1) >> 16)) : (bf16)0.0f;
+                        bw[2] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16)) : (bf16)0.0f;
+                    }
+                }
+                f32x4 z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, ones, z, 0, 0, 0);
+            }
+        }
         multiply(no{}, false, 0);                                                 // K-tile 1 was requested at the previous tile boundary
         {
             const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
@@ -281,13 +310,14 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             }
         };
         s_barrier_lgkm();
-        if (has_next) set_src(nm0, nn0, nbz);                                      // addresses first, loads after: no reload lands behind a DMA
+        if (has_next) { set_src(nm0, nn0, nbz); if (!RESK) load_bias(nn0); }       // addresses first, loads after: no reload lands behind a DMA
         if (use_res) { if (interior) load_residual(yes{}, 0); else load_residual(no{}, 0); }
         multiply(yes{}, has_next, 0);                                              // last K-tile; the next tile's first one goes out
         const unsigned long long ts1 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
         s_barrier_lgkm();                                                          // every wave is done with the stage just multiplied: it
                                                                                    // receives the next tile's SECOND K-tile inside pass 0
         // One 32-row MFMA tile per pass through this wave's private 4 KiB of staging.
+        if (RESK && has_next) load_bias(nn0);          // (with a residual the registers are tighter during the last K-tile: fetched here, still ahead of the stores)
         auto epilogue = [&](auto res_tag, auto int_tag) {
             constexpr bool RES = decltype(res_tag)::value, INT = decltype(int_tag)::value;
 #pragma unroll
