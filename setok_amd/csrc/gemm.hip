@@ -13,7 +13,9 @@
 //    in gemm_persist.hip, every smaller bf16 -> bf16 problem with N % 64 == 0 to that file's 64x64 eight-stage
 //    LDS-DMA kernel (a handful of images is latency-bound: 257 x 3072 x 1024 takes 9 us there against 36 us
 //    here; one-image encode 9.0 -> 3.8 ms); the kernel below serves fp32 outputs (Gram matrix), batches and
-//    odd N.  All three give the same bits for the same row (bias as accumulator init, ascending k).
+//    odd N.  The persistent and the 64x64 kernel give the same bits for the same row (bias as accumulator init, ascending k,
+//    v_mfma_f32_16x16x32_bf16): a sample alone equals the sample inside a batch.  The kernel below keeps the 32x32x16 shape; for a
+//    given layer it is either always or never the one that runs (the choice depends on N / output type / batching, not on M).
 //  * fp32 kernel  (parity mode): 64x64x16 block tile, 4 waves, v_mfma_f32_32x32x2_f32 — bit-for-bit a
 //    k-ordered fmaf chain, so results do not depend on tile geometry.
 #include "common.h"
