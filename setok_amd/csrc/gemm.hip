@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[i][j][r];
                 if (g.act == SETOK_ACT_QUICK_GELU) v = FAST_ACT ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * v)) : v / (1.0f + expf(-1.702f * v));
-                else if (g.act == SETOK_ACT_GELU_ERF) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                else if (g.act == SETOK_ACT_GELU_ERF) v = FAST_ACT ? gelu_erf_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                 const int64_t o = (int64_t)row * g.ldc + col;
                 if (R) v = round_to<TO>(v) + ld_out<TO>(R + o);           // Linear output rounded to TO first (no-op for fp32)
                 Elem<TO>::st(C + o, v);

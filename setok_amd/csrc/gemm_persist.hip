@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[2 * h + tt][j][e];
                             if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
-                            else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                            else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                             v[e] = (bf16)x;
                         }
                         // row tt * 16 + l15 of the pass, columns j * 16 + 4 * g4 .. + 3: 16-byte slot j * 2 + (g4 >> 1), its half g4 & 1
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
             for (int e = 0; e < 4; ++e) {
                 float x = acc[t][j][e];
                 if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
-                else if (ACT == SETOK_ACT_GELU_ERF) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+                else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                 v[e] = (bf16)x;
             }
             const int row = wm * 32 + t * 16 + l15;                 // columns wn * 32 + j * 16 + 4 * g4 .. + 3
