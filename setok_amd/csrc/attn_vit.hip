@@ -221,7 +221,16 @@ int launch_cross(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const
 int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, int Dh, float scale) {
     if ((Dh != 64 && Dh != 48) || T < 1 || (size_t)((T + 31) & ~31) * ROWB * 2 > 160 * 1024) return SETOK_EUNSUPPORTED;
     const int nq = (T + 31) >> 5;
+    // K + V of more than 80 KiB leave room for one workgroup per CU only: then a wave per query tile (up to 12) instead of 8 waves taking
+    // two rounds (T = 324, the decoder's 18 x 18 queries: 11 tiles on 8 waves = 2 rounds with 5 idle waves in the second)
+    const bool one_wg = (size_t)((T + 31) & ~31) * ROWB * 2 > 80 * 1024;
     if (Dh == 48) {                                                   // the reconstruction decoder's ViT blocks (768 / 16 heads)
+        if (one_wg && nq >= 9 && nq <= 12) {
+            if (nq == 9) return launch<9, 48>(s, qkv, out, n_imgs, T, H, scale);
+            if (nq == 10) return launch<10, 48>(s, qkv, out, n_imgs, T, H, scale);
+            if (nq == 11) return launch<11, 48>(s, qkv, out, n_imgs, T, H, scale);
+            return launch<12, 48>(s, qkv, out, n_imgs, T, H, scale);
+        }
         if (nq >= 8) return launch<8, 48>(s, qkv, out, n_imgs, T, H, scale);
         if (nq >= 4) return launch<4, 48>(s, qkv, out, n_imgs, T, H, scale);
         return launch<1, 48>(s, qkv, out, n_imgs, T, H, scale);
