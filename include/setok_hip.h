@@ -242,6 +242,12 @@ int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_
 int setok_attention_causal(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Dh,
                            float scale);
 
+/* The language-model loss of SetokimLlamaForCausalLM.forward (setokim_llama.py:145-160): logits (B*T rows of V, row stride ld) are read as
+ * fp32; position t predicts labels[t + 1]; positions with attention_mask[t + 1] == 0 (NULL = none) or labels[t + 1] == ignore_index are left
+ * out; out[0] = mean cross entropy over the rest (NaN if none), out[1] = their number.  row_ws: 2*B*T floats of workspace.  Deterministic. */
+int setok_lm_loss(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels, const uint8_t* attention_mask, int B, int T,
+                  int V, int ignore_index, float* row_ws, float* out);
+
 #ifdef __cplusplus
 }
 #endif

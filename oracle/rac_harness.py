@@ -325,3 +325,20 @@ def rac_head_grads(tok, feats_list, upstream_list, k=None, threshold=None, noise
     grads = {n: p.grad.detach().clone() for n, p in tok.named_parameters()
              if p.grad is not None and not n.startswith("image_feature_encoder")}
     return grads, counts
+
+
+def rac_lm_loss(logits, new_labels, attention_mask):
+    """The reference's own loss statements (src/model/language_model/setokim_llama.py:145-160, inside `SetokimLlamaForCausalLM.forward`,
+    which cannot be instantiated here) executed as they stand: the lines are read from the reference file at call time, dedented and run
+    with `logits`, `new_labels`, `attention_mask`, `labels` bound.  Nothing of the file is kept in this repository."""
+    import textwrap
+    import torch
+    from torch import nn
+    path = os.path.join(REF_ROOT, "src", "model", "language_model", "setokim_llama.py")
+    lines = open(path).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.strip() == "loss = None")
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("diff_loss_list"))
+    code = textwrap.dedent("\n".join(lines[start:end]))
+    ns = {"logits": logits, "new_labels": new_labels, "attention_mask": attention_mask, "labels": new_labels, "nn": nn, "torch": torch}
+    exec(compile(code, path, "exec"), ns)
+    return ns["loss"]

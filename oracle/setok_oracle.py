@@ -883,3 +883,33 @@ def planted_features(N: int, C: int, m: int, seed: int = 0, centre_std: float = 
     region = torch.cdist(pts, sites).argmin(dim=-1)
     centres = torch.randn(m, C, generator=g) * centre_std
     return centres[region] + torch.randn(N, C, generator=g) * noise_std
+
+
+def lm_loss(logits: Tensor, new_labels: Tensor, attention_mask: Optional[Tensor]) -> Tensor:
+    """The language-model loss of SetokimLlamaForCausalLM.forward, src/model/language_model/setokim_llama.py:145-160, call for call:
+    `logits.float()`, shift so that tokens < n predict n, keep the positions whose NEXT token is attended (`attention_mask[..., 1:] != 0`),
+    `nn.CrossEntropyLoss()` (ignore_index -100, mean)."""
+    logits = logits.float()                                                          # :147
+    if attention_mask is not None:                                                   # :149
+        shift_attention_mask = attention_mask[..., 1:]                               # :150
+        shift_logits = logits[..., :-1, :][shift_attention_mask != 0].contiguous()   # :151
+        shift_labels = new_labels[..., 1:][shift_attention_mask != 0].contiguous()   # :152
+    else:
+        shift_logits = logits[..., :-1, :].contiguous()                              # :154
+        shift_labels = new_labels[..., 1:].contiguous()                              # :155
+    loss_fct = torch.nn.CrossEntropyLoss()                                           # :157
+    return loss_fct(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.view(-1))      # :158-160
+
+
+def lm_loss_inputs(seed, B, T, V, padding):
+    """Seeded logits (bf16-representable), labels with IGNORE_INDEX stretches (the prompt part) and an attention mask with padding."""
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(B, T, V, generator=g) * 3).bfloat16().float()
+    labels = torch.randint(0, V, (B, T), generator=g)
+    labels[:, : T // 3] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    if padding == "right":
+        for b in range(B): am[b, T - 1 - b:] = 0
+    elif padding == "left":
+        for b in range(B): am[b, : b + 1] = 0
+    return logits, labels, (None if padding == "none" else am)

@@ -307,6 +307,78 @@ __global__ __launch_bounds__(256) void attn_causal_kernel(const bf16* __restrict
 
 }  // namespace
 
+// ---- language-model loss -------------------------------------------------------------------------------------------------------------------
+// setokim_llama.py:145-160: logits.float(); position t predicts token t + 1; positions whose NEXT token is padding (attention_mask[t + 1] == 0)
+// are dropped, CrossEntropyLoss() then ignores label -100 and averages over the rest.  One workgroup per (sequence, position): a dropped /
+// ignored position costs nothing (its logits row is never read); the others make two passes over their row (max, then sum of exponentials:
+// the re-read hits L2) in fp32.  A label outside [0, V) that is not the ignore index yields NaN (torch raises there).
+template <typename T>
+__global__ __launch_bounds__(256) void lm_loss_rows_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                           const uint8_t* __restrict__ amask, int Tn, int V, int ignore_index,
+                                                           float* __restrict__ loss_row, float* __restrict__ valid_row) {
+    constexpr int VE = Elem<T>::VEC;
+    const int row = blockIdx.x, t = row % Tn, tid = threadIdx.x;
+    __shared__ float red[4];
+    bool valid = t + 1 < Tn;
+    int64_t target = 0;
+    if (valid) {
+        target = labels[row + 1];
+        valid = (!amask || amask[row + 1] != 0) && target != (int64_t)ignore_index;
+    }
+    if (!valid) {
+        if (tid == 0) { loss_row[row] = 0.f; valid_row[row] = 0.f; }
+        return;
+    }
+    const T* x = logits + (int64_t)row * ld;
+    const int nvec = V / VE;
+    float buf[VE];
+    float m = -INFINITY;
+    for (int c = tid; c < nvec; c += 256) {
+        ld_vec<T>(x + (int64_t)c * VE, buf);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) m = fmaxf(m, buf[i]);
+    }
+    for (int c = nvec * VE + tid; c < V; c += 256) m = fmaxf(m, Elem<T>::ld(x + c));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid; c < nvec; c += 256) {
+        ld_vec<T>(x + (int64_t)c * VE, buf);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) sum += expf(buf[i] - m);
+    }
+    for (int c = nvec * VE + tid; c < V; c += 256) sum += expf(Elem<T>::ld(x + c) - m);
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        const bool in_range = target >= 0 && target < (int64_t)V;
+        loss_row[row] = in_range ? (m + logf(tot)) - Elem<T>::ld(x + target) : NAN;
+        valid_row[row] = 1.f;
+    }
+}
+
+// fixed-order mean of the per-position losses: thread i sums rows i, i + 256, ... then a tree over the 256 partial sums
+__global__ __launch_bounds__(256) void lm_loss_reduce_kernel(const float* __restrict__ loss_row, const float* __restrict__ valid_row, int rows,
+                                                             float* __restrict__ out) {
+    __shared__ float sl[256], sc[256];
+    const int tid = threadIdx.x;
+    float a = 0.f, c = 0.f;
+    for (int r = tid; r < rows; r += 256) { a += loss_row[r]; c += valid_row[r]; }
+    sl[tid] = a; sc[tid] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sl[tid] += sl[tid + o]; sc[tid] += sc[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { out[0] = sl[0] / sc[0]; out[1] = sc[0]; }        // 0 / 0 = NaN when nothing is valid: what torch's mean over an empty set gives
+}
+
 #define LL_DISPATCH(NAME, CALL_BF16, CALL_F32)                                 \
     if (dtype == SETOK_BF16) { CALL_BF16; }                                    \
     else if (dtype == SETOK_F32) { CALL_F32; }                                 \
@@ -383,5 +455,22 @@ extern "C" int setok_attention_causal(void* stream, int dtype, const void* qkv, 
                 (attn_causal_generic_kernel<bf16><<<grid, 64, smem, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, Dh, scale)),
                 (attn_causal_generic_kernel<float><<<grid, 64, smem, s>>>((const float*)qkv, key_mask, (float*)out, T, H, Dh, scale)));
     SETOK_CHECK_LAUNCH("setok_attention_causal");
+    return SETOK_OK;
+}
+
+extern "C" int setok_lm_loss(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels, const uint8_t* attention_mask, int B,
+                             int T, int V, int ignore_index, float* row_ws, float* out) {
+    SETOK_CHECK_ARG(logits && labels && row_ws && out, "setok_lm_loss: null operand");
+    SETOK_CHECK_ARG(B >= 0 && T > 0 && V > 0 && ld >= V, "setok_lm_loss: bad shape B=%d T=%d V=%d", B, T, V);
+    SETOK_CHECK_ARG(ld % 8 == 0, "setok_lm_loss: the logits row stride must be a multiple of 8 elements");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * T;
+    if (rows > 0) {
+        LL_DISPATCH("setok_lm_loss", (lm_loss_rows_kernel<bf16><<<rows, 256, 0, s>>>((const bf16*)logits, ld, labels, attention_mask, T, V, ignore_index, row_ws, row_ws + rows)),
+                    (lm_loss_rows_kernel<float><<<rows, 256, 0, s>>>((const float*)logits, ld, labels, attention_mask, T, V, ignore_index, row_ws, row_ws + rows)));
+        SETOK_CHECK_LAUNCH("setok_lm_loss(rows)");
+    }
+    lm_loss_reduce_kernel<<<1, 256, 0, s>>>(row_ws, row_ws + rows, rows, out);
+    SETOK_CHECK_LAUNCH("setok_lm_loss(reduce)");
     return SETOK_OK;
 }

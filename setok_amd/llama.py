@@ -141,9 +141,11 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
 
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, labels=None, comp_images=None,
-                last_token_only: bool = False):
+                last_token_only: bool = False, return_loss: bool = False):
         """Returns (logits, new_labels, attention_mask): logits (B, T', vocab) — or (B, vocab) for every sequence's last token with
-        `last_token_only` (what a generation step after the prefill needs) — on the spliced sequence of length T'."""
+        `last_token_only` (what a generation step after the prefill needs) — on the spliced sequence of length T'.  With `return_loss`
+        (and labels) a fourth element is the language-model loss of setokim_llama.py:145-160 (shifted cross entropy over the positions whose
+        next token is neither padding nor IGNORE_INDEX), as a 0-d fp32 tensor; the diffusion term of :163-180 is not part of this path."""
         new_labels = labels
         self._last_features = None
         if inputs_embeds is None:
@@ -163,4 +165,8 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
             rows = hidden[torch.arange(B, device=hidden.device), last].contiguous()
             return ops.linear(rows, w), new_labels, attention_mask
         logits = ops.linear(hidden.reshape(B * T, D), w).reshape(B, T, -1)         # :143
+        if return_loss:
+            if new_labels is None:
+                raise ValueError("return_loss needs labels")
+            return logits, new_labels, attention_mask, ops.lm_loss(logits, new_labels, attention_mask)[0]      # :145-160
         return logits, new_labels, attention_mask

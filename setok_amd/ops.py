@@ -401,6 +401,20 @@ def swiglu(gate_up: Tensor) -> Tensor:
     return out
 
 
+def lm_loss(logits: Tensor, labels: Tensor, attention_mask: Optional[Tensor], ignore_index: int = -100) -> Tensor:
+    """The shifted, padding-masked cross entropy of setokim_llama.py:145-160.  logits (B, T, V) fp32 / bf16 (read as fp32), labels (B, T)
+    int64, attention_mask (B, T) or None.  Returns a 2-element fp32 tensor: [mean loss, number of positions that counted]."""
+    B, T, V = logits.shape
+    lg = logits.reshape(B * T, V)
+    assert lg.stride(1) == 1
+    lab = labels.to(device=logits.device, dtype=torch.int64).reshape(B * T).contiguous()
+    am = None if attention_mask is None else (attention_mask.to(logits.device) != 0).to(torch.uint8).reshape(B * T).contiguous()
+    ws = torch.empty(2 * B * T, dtype=torch.float32, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _lib.call("setok_lm_loss", _stream(), _code(logits.dtype), lg.data_ptr(), lg.stride(0), _p(lab), _p(am), B, T, V, ignore_index, _p(ws), _p(out))
+    return out
+
+
 def attention_causal(qkv: Tensor, key_mask: Optional[Tensor], B: int, T: int, H: int, Dh: int, scale: float) -> Tensor:
     assert qkv.shape == (B * T, 3 * H * Dh)
     if key_mask is not None:

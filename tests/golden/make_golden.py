@@ -317,8 +317,24 @@ def gen_llama():
     save("llama", **arrs)
 
 
+LM_LOSS_CASES = {"plain": (0, 2, 9, 37, "none"), "right_pad": (1, 3, 12, 50, "right"), "left_pad_ignored": (2, 3, 11, 64, "left")}
+
+
+def gen_lm_loss():
+    """The language-model loss: the reference's own statements (setokim_llama.py:145-160) executed by rac_harness.rac_lm_loss on seeded
+    logits / labels / masks.  Inputs regenerate from the seed (oracle.lm_loss_inputs); stored: the loss."""
+    arrs = {}
+    for name, (seed, B, T, V, padding) in LM_LOSS_CASES.items():
+        logits, labels, am = O.lm_loss_inputs(seed, B, T, V, padding)
+        loss = R.rac_lm_loss(logits, labels, am)
+        arrs[name + ":spec"] = np.array([seed, B, T, V]); arrs[name + ":padding"] = np.array(padding)
+        arrs[name + ":loss"] = npy(loss.reshape(1))
+        print(name, "loss", float(loss))
+    save("lm_loss", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads", "llama"]
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads", "llama", "lm_loss"]
     if "detok" in which:
         gen_detok()
     if "splice" in which:
@@ -327,6 +343,8 @@ if __name__ == "__main__":
         gen_head_grads()
     if "llama" in which:
         gen_llama()
+    if "lm_loss" in which:
+        gen_lm_loss()
     if "head_small" in which:
         gen_head_small()
     if "cluster_full" in which:

@@ -143,3 +143,40 @@ def test_setokim_forward_splices_then_prefills():
     _, ref = O.llama_forward(sd, lc, remb, ram, None)
     assert torch.equal(new_am.cpu(), ram) and torch.equal(new_labels.cpu(), rlab)
     assert _rel(lg.cpu()[ram.bool()], ref[ram.bool()]) < 1e-4
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-6)])
+def test_lm_loss_matches_oracle_and_golden(golden_dir, dt, tol):
+    """setok_lm_loss against the oracle (setokim_llama.py:145-160) and, in fp32, the reference's own value; the logits are bf16-representable, so
+    both dtypes read the same numbers.  Also: a strided logits view, no valid position -> NaN, and the count."""
+    z = np.load(os.path.join(golden_dir, "lm_loss.npz"))
+    for c in sorted({k.split(":")[0] for k in z.files}):
+        seed, B, T, V = (int(v) for v in z[c + ":spec"])
+        logits, labels, am = O.lm_loss_inputs(seed, B, T, V, str(z[c + ":padding"]))
+        ref = float(O.lm_loss(logits, labels, am))
+        Vp = (V + 7) // 8 * 8 + 8                                            # rows with a stride (the kernel takes ld)
+        buf = torch.zeros(B, T, Vp, dtype=dt, device=DEV)
+        buf[..., :V] = logits.to(dt).to(DEV)
+        out = ops.lm_loss(buf[..., :V], labels.to(DEV), None if am is None else am.to(DEV)).cpu()
+        assert abs(float(out[0]) - ref) <= tol * abs(ref) + 1e-6
+        assert abs(float(out[0]) - float(z[c + ":loss"][0])) <= 2e-6 * abs(ref) + 1e-6
+        am1 = torch.ones(B, T, dtype=torch.long) if am is None else am
+        n_ref = int(((am1[:, 1:] != 0) & (labels[:, 1:] != -100)).sum())
+        assert int(out[1]) == n_ref
+    none = ops.lm_loss(buf[..., :V], torch.full((B, T), -100), None).cpu()
+    assert bool(torch.isnan(none[0])) and int(none[1]) == 0
+
+
+def test_prefill_returns_the_lm_loss():
+    cfg = dict(vocab_size=96, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1, rms_norm_eps=1e-5)
+    torch.manual_seed(0)
+    m = SetokimLlamaPrefill(cfg).to(device=DEV, dtype=torch.bfloat16).eval()
+    B, T = 3, 20
+    x = torch.randn(B, T, 128).to(device=DEV, dtype=torch.bfloat16)
+    labels = torch.randint(0, 96, (B, T)); labels[:, :5] = -100
+    am = torch.ones(B, T, dtype=torch.long); am[1, 15:] = 0
+    logits, nl, _, loss = m(inputs_embeds=x, attention_mask=am.to(DEV), labels=labels.to(DEV), return_loss=True)
+    ref = O.lm_loss(logits.float().cpu(), labels, am)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    with pytest.raises(ValueError):
+        m(inputs_embeds=x, attention_mask=am.to(DEV), return_loss=True)

@@ -288,3 +288,15 @@ def test_llama_prefill_matches_hf(golden_dir, name):
     v = am.bool()
     torch.testing.assert_close(h[v], hidden[v], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(lg[v], logits[v], rtol=1e-5, atol=1e-5)
+
+
+def test_lm_loss_matches_reference(golden_dir):
+    """setokim_llama.py:145-160 — the oracle's restatement against the loss the reference's own statements gave (tests/golden/lm_loss.npz)."""
+    z = np.load(os.path.join(golden_dir, "lm_loss.npz"))
+    cases = sorted({k.split(":")[0] for k in z.files})
+    assert len(cases) == 3
+    for c in cases:
+        seed, B, T, V = (int(v) for v in z[c + ":spec"])
+        logits, labels, am = O.lm_loss_inputs(seed, B, T, V, str(z[c + ":padding"]))
+        got = O.lm_loss(logits, labels, am)
+        assert abs(float(got) - float(z[c + ":loss"][0])) <= 1e-6 * abs(float(z[c + ":loss"][0]))

@@ -163,3 +163,10 @@ def test_checkpoint_key_names_load_in_the_reference_and_back(tok, tmp_path):
     res = C.load_pretrained_tokenizer(mine, theirs)
     assert res.unexpected_keys == ["decoder_norm.weight"]
     assert all(torch.equal(tok.state_dict()[k], mine.state_dict()[k]) for k in head)
+
+
+def test_lm_loss_restatement_vs_reference_statements_live():
+    """The oracle's lm_loss against the reference's own loss statements executed from the reference file (rac_harness.rac_lm_loss)."""
+    for seed, B, T, V, padding in ((0, 2, 9, 37, "none"), (5, 4, 17, 101, "right"), (6, 3, 13, 64, "left")):
+        logits, labels, am = O.lm_loss_inputs(seed, B, T, V, padding)
+        assert torch.equal(R.rac_lm_loss(logits, labels, am), O.lm_loss(logits, labels, am))
