@@ -57,7 +57,7 @@ WORKLOADS = {
                                "master weights"),
     "cfg5": (224, 32, False, "cfg5: full Setokim forward at Vicuna-7B dims (32 layers, hidden 4096, 32 heads x 128, SwiGLU 11008, vocab 32000; random-init "
                               "bf16 weights): 32 images -> SeTok encode (cfg2 model) -> mm_in_projector -> splice into 512-token prompts -> LLM prefill -> "
-                              "logits at every position (setokim_llama.py:94-143, no loss)"),
+                              "logits at every position -> language-model loss over the answer part (setokim_llama.py:94-160; the diffusion term is out of scope)"),
     "cfg3": (224, 256, True, "cfg3: cfg2 encode + reconstruction decoder (SetokDeTokenizer: token_feat_dim 4096 -> Q-Former 768/12 heads/6 layers, "
                               "324 queries (image_size 256 / 14), cross-attention every 2nd layer -> 16 x ViT block 768/16 heads -> LayerNorm); "
                               "no loss (the reference's GANLoss path is out of scope)"),
@@ -217,6 +217,8 @@ def main():
         ids[:, 17] = -200                                         # one image placeholder per prompt (IMAGE_TOKEN_INDEX)
         ids = ids.to(dev)
         amask = torch.ones(B, T_TXT, dtype=torch.bool, device=dev)
+        lm_labels = ids.clone()
+        lm_labels[:, :64] = -100                                  # the prompt part (IGNORE_INDEX); the image positions are set by the splice
         log("LLM on device")
     trainer = None
     if args.workload == "cfg4":
@@ -225,8 +227,8 @@ def main():
 
     def step():
         if llm is not None:
-            logits, _, _ = llm(input_ids=ids, attention_mask=amask, comp_images=images)
-            step.logits = logits
+            logits, _, _, loss = llm(input_ids=ids, attention_mask=amask, labels=lm_labels, comp_images=images, return_loss=True)
+            step.logits, step.loss = logits, loss
             return llm._last_features
         if trainer is not None:
             tokens, ctx = trainer.forward(images)
