@@ -1,8 +1,13 @@
 #!/usr/bin/env python
 """bench.py — SeTok encode_images throughput on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f32] [--workload cfg2|cfg3|cfg4|cfg4-forward|cfg5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Started WITHOUT a launcher (`WORLD_SIZE` unset) and with --gpus N > 1, the script re-executes itself under
+`torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (the reference's own parallelism is data
+parallelism under a launcher: scripts/train_setok.sh:38-39, scripts/zero2.json:16-22); it never prints `n_gpus: 1` for a run
+that asked for more, and exits with an error if fewer than N GPUs are visible.
 
 A "step" is one pass of the hot path — encode_images = ViT-L/14 tower -> +2-D pos -> DPC-kNN dynamic
 clustering -> per-cluster encoder + mean -> inter-cluster encoder -> out Linear -> mm_in_projector
@@ -30,6 +35,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3            # fp32-input MFMA (= the fp32 vector rate), MI355X_MICROARCH.md: the parity-exact mode's GEMMs
 PEAK_HBM_GBS = 8000.0              # HBM3E, MI355X_MICROARCH.md
 MFMA_ONLY_RANDOM_TFLOPS = 2080.0   # measured: tools/micro/mfma_peak.hip (register-resident loop of v_mfma_f32_16x16x32_bf16 — the shape the GEMM
                                    # kernels use — on random bf16 operands, power-managed to 2.11 GHz / 1.37 kW; 2455 TFLOP/s at 2.40 GHz on
@@ -71,12 +77,12 @@ def build_decoder(device):
     return det.to(device=device, dtype=torch.bfloat16).eval()
 
 
-def build_model(device, img=IMG):
+def build_model(device, img=IMG, dtype=torch.bfloat16, select_layer=-2):
     import setok_amd
     from setok_amd.synthetic import init_synthetic_
     vit = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
                image_size=img, patch_size=PATCH)
-    tok = setok_amd.SetokTokenizer(vision_tower=vit, mm_vision_select_layer=-2, hidden_dim=1024, token_feat_dim=4096,
+    tok = setok_amd.SetokTokenizer(vision_tower=vit, mm_vision_select_layer=select_layer, hidden_dim=1024, token_feat_dim=4096,
                                    min_cluster_num=64, threshold=THRESHOLD, nheads=2, dim_feedforward=4096)
     init_synthetic_(tok, tower_seed=0, head_seed=1)
     proj = setok_amd.build_vision_projector("mlp2x_gelu", mm_hidden_size=4096, hidden_size=4096)
@@ -84,7 +90,7 @@ def build_model(device, img=IMG):
     for m in proj:
         if isinstance(m, torch.nn.Linear):
             torch.nn.init.xavier_uniform_(m.weight); torch.nn.init.zeros_(m.bias)
-    return tok.to(device=device, dtype=torch.bfloat16).eval(), proj.to(device=device, dtype=torch.bfloat16).eval()
+    return tok.to(device=device, dtype=dtype).eval(), proj.to(device=device, dtype=dtype).eval()
 
 
 def cpu_baseline(tok, proj, n_images=16, reps=3):
@@ -159,6 +165,66 @@ def gpu_telemetry(step, device_index, n_steps=6):
     return {"sclk_mhz_under_load": clk, "socket_power_w_under_load": round(sorted(pw)[len(pw) // 2], 0) if pw else None}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks.  Re-executes this script under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1 at a free port); the re-executed ranks see WORLD_SIZE and take the normal path."""
+    import socket
+    if not args.launch_check:
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} asked for, {n_vis} GPU(s) visible: refusing to report fewer ranks than asked")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no launcher in the environment: " + " ".join(cmd))
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def launch_check(rank, world, local):
+    """The launcher and the multi-rank bookkeeping on CPU (gloo): every rank reports itself, rank 0 prints what a bench line would carry.
+    Used by tests/test_parallel_cpu.py (`python bench.py --gpus 2 --launch-check`)."""
+    import torch.distributed as dist
+    from setok_amd.parallel import max_over_ranks
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dt = max_over_ranks(0.01 * (rank + 1))
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, dict(rank=rank, local_rank=local, seconds=0.01 * (rank + 1)))
+    else:
+        per_rank = [dict(rank=0, local_rank=0, seconds=0.01)]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": per_rank, "slowest_seconds": dt}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic():
+    """HBM bytes per launch from the PMC passes of this command (profiles/rNN_traffic.json, written by tools/gemm_traffic.py from
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; the newest round's file).  A missing file is reported as such; a file that is there
+    and cannot be read is an error — evidence is never dropped silently."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not files:
+        return None, "no profiles/rNN_traffic.json in the tree"
+    with open(files[-1]) as f:
+        d = json.load(f)
+    for key in ("gemm", "clustering"):
+        if key not in d or "traffic_bytes_per_launch" not in d[key]:
+            raise KeyError(f"{files[-1]}: no {key}.traffic_bytes_per_launch")
+    d["file"] = os.path.relpath(files[-1], ROOT)
+    return d, None
+
+
+def gemm_class(p):
+    return p["kernel"].split(":", 1)[1] if ":" in p["kernel"] else "all"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,17 +232,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
+                    help="bf16 = the BASELINE metric's precision; f32 = the parity-exact mode (bit-exact cluster indices, 1e-4 features)")
+    ap.add_argument("--select-layer", type=int, default=-2,
+                    help="hidden_states index the tower returns: -2 = the reference classes' default (tokenizer.py:18, 23 of 24 layers run); "
+                         "-1 = what the reference's launch scripts pass (scripts/pretrain_mm_proj.sh:43, all 24 layers)")
+    ap.add_argument("--launch-check", action="store_true", help="CPU-only check of the self-launcher and the rank bookkeeping (gloo)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
                     help="cfg2 is the BASELINE.json metric; the others are additional measurements (no cpu_baseline leg)")
     args = ap.parse_args()
     img, b_default, with_decoder, workload_desc = WORKLOADS[args.workload]
     if args.batch is None:
         args.batch = b_default
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                   # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: the launcher and the flag disagree")
+    if args.launch_check:
+        return launch_check(rank, world, local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -189,12 +269,16 @@ def main():
     import setok_amd
     from setok_amd import ops
     log(f"rank {rank}/{world}: building model")
-    tok, proj = build_model(dev, img)
+    if args.select_layer != -2:
+        workload_desc = workload_desc.replace("23 of 24 layers, select_layer=-2", f"select_layer={args.select_layer}")
+    if args.dtype == "f32":
+        workload_desc += "; fp32 parity mode (exact-f32 MFMA GEMMs)"
+    tok, proj = build_model(dev, img, dtype, args.select_layer)
     det = build_decoder(dev) if with_decoder else None
     log("model on device")
     B = args.batch
     g = torch.Generator().manual_seed(3 + rank)
-    images = torch.randn(B, 3, img, img, generator=g).to(device=dev, dtype=torch.bfloat16)   # resident in HBM
+    images = torch.randn(B, 3, img, img, generator=g).to(device=dev, dtype=dtype)   # resident in HBM
 
     llm = None
     if args.workload == "cfg5":
@@ -202,7 +286,7 @@ def main():
         lcfg = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
                     num_key_value_heads=32, rms_norm_eps=1e-5, rope_theta=10000.0)
         with torch.device(dev):
-            llm = SetokimLlamaPrefill(lcfg, vision_tower=tok, mm_in_projector=proj).to(torch.bfloat16)
+            llm = SetokimLlamaPrefill(lcfg, vision_tower=tok, mm_in_projector=proj).to(dtype)
         gl = torch.Generator(device=dev).manual_seed(11)
         for n_, p_ in llm.named_parameters():
             if n_.startswith(("vision_tower.", "mm_in_projector.")):
@@ -256,24 +340,54 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     prof = ops.profile_stop()
-    log(f"timed {args.steps} steps in {dt:.3f} s")
+    log(f"timed {args.steps} steps in {dt_local:.3f} s")
     from setok_amd.parallel import max_over_ranks
-    dt = max_over_ranks(dt, device=dev)            # wall time of the slowest rank
+    dt = max_over_ranks(dt_local, device=dev)            # wall time of the slowest rank
+
+    counts = out.counts
+    mine = dict(rank=rank, ms_per_step=round(dt_local / args.steps * 1e3, 3), tokens_per_image=round(sum(counts) / len(counts), 2))
+    if trainer is not None:
+        mine.update(trainer.comm_stats())
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
+    # the select_layer = -1 number beside the -2 one (the reference's launch scripts run all 24 layers): a few extra steps, untimed above
+    other = None
+    if rank == 0 and args.workload == "cfg2" and world == 1 and args.select_layer == -2:
+        tower = tok.image_feature_encoder
+        tower.select_layer = -1
+        setok_amd.encode_images(tok, proj, images); torch.cuda.synchronize()
+        n_o = max(2, min(args.steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(n_o):
+            o2 = setok_amd.encode_images(tok, proj, images)
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t1) / n_o
+        other = {"select_layer": -1, "layers_run": 24, "images_per_s": round(B / d1, 2), "ms_per_step": round(d1 * 1e3, 3), "steps": n_o,
+                 "tokens_per_image_mean": round(sum(o2.counts) / len(o2.counts), 2)}
+        tower.select_layer = -2
 
     telemetry = gpu_telemetry(step, local) if rank == 0 else None
-    counts = out.counts
-    traffic = None                  # HBM bytes per GEMM launch from the PMC passes of the same command (profiles/)
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_note = load_traffic()
     if rank == 0:
-        gemm = [p for p in prof if p["kernel"] == "gemm_bf16"]
+        gname = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        gemm = [p for p in prof if p["kernel"].split(":")[0] == gname]
         g_ms = sum(p["ms"] for p in gemm)
         g_fl = sum(p["flops"] for p in gemm)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        classes = {}
+        for p_ in gemm:
+            c = classes.setdefault(gemm_class(p_), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            c["launches"] += 1; c["ms"] += p_["ms"]; c["flops"] += p_["flops"]; c["bytes"] += p_.get("bytes", 0.0)
+        per_class = {k: {"launches_per_step": v["launches"] // max(args.steps, 1), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                         "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                         "algorithmic_mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 1)} for k, v in sorted(classes.items())}
+        alg_bytes = sum(p_.get("bytes", 0.0) for p_ in gemm) / max(len(gemm), 1)
         res = {
             "metric": "images/s SeTok encode (ViT-L/14, 224^2, dyn-k)" if args.workload == "cfg2" else f"images/s SeTok {args.workload}",
             "value": round(world * B * args.steps / dt, 2),
@@ -281,32 +395,51 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_desc, "batch_per_gpu": B, "global_batch": world * B,
                        "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
-                       "sharding": f"dp{world} (images sharded, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<*> (bf16 MFMA GEMM of every large Linear)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                       "sharding": f"dp{world} (images sharded, no data-path collective)",
+                       "per_rank": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"]},
+            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<*> (bf16 MFMA GEMM of every large Linear)" if args.dtype == "bf16"
+                         else "gemm_f32_kernel (exact-f32 MFMA GEMM, parity mode)",
+                         "achieved": round(achieved, 1), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": traffic["gemm"]["traffic_bytes_per_launch"] if traffic else None,
+                         "algorithmic_bytes_per_launch": round(alg_bytes),
                          "launches_per_step": len(gemm) // max(args.steps, 1),
                          "avg_launch_ms": round(g_ms / max(len(gemm), 1), 4),
                          "avg_launch_gflop": round(g_fl / max(len(gemm), 1) / 1e9, 2),
-                         "gemm_share_of_step": round(g_ms / (dt * 1e3), 3)},
+                         "gemm_share_of_step": round(g_ms / (dt * 1e3), 3),
+                         "per_class": per_class},
         }
+        if traffic:
+            res["roofline"]["traffic_source"] = traffic["file"]
+            res["roofline"]["traffic_per_class"] = traffic["gemm"].get("per_class")
+        else:
+            res["roofline"]["traffic_note"] = traffic_note
         clus = [p for p in prof if p["kernel"] == "cluster_dpc_knn"]
         if clus:
             c_ms = sum(p["ms"] for p in clus) / len(clus)
-            c_gbs = sum(p["flops"] for p in clus) / len(clus) / (c_ms * 1e-3) / 1e9          # the "flops" slot holds algorithmic BYTES here
-            res["roofline_clustering"] = {"bound": "hbm", "kernel": "setok_cluster_dpc_knn (Gram + kNN density + delta/score + select + assign)",
+            c_bytes = sum(p["flops"] for p in clus) / len(clus)                              # the "flops" slot holds algorithmic BYTES here
+            c_gbs = c_bytes / (c_ms * 1e-3) / 1e9
+            gram_tf = 2.0 * B * (img // PATCH) ** 4 * 1024 / (c_ms * 1e-3) / 1e12           # the Gram's 2 N^2 C per image over the whole call
+            res["roofline_clustering"] = {"bound": "hbm", "kernel": "setok_cluster_dpc_knn (Gram -> kNN density -> delta/score -> centres -> assignment)",
                                           "achieved": round(c_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(c_gbs / PEAK_HBM_GBS, 4),
+                                          "algorithmic_bytes_per_call": round(c_bytes),
+                                          "traffic": traffic["clustering"]["traffic_bytes_per_launch"] if traffic else None,
+                                          "gram_tflops_over_the_call": round(gram_tf, 1),
                                           "ms_per_call": round(c_ms, 4), "share_of_step": round(c_ms * len(clus) / (dt * 1e3), 4)}
-        res["roofline"]["mfma_only_random_operands_tflops"] = MFMA_ONLY_RANDOM_TFLOPS
-        res["roofline"]["frac_of_mfma_only_random"] = round(achieved / MFMA_ONLY_RANDOM_TFLOPS, 4)
+        if args.dtype == "bf16":
+            res["roofline"]["mfma_only_random_operands_tflops"] = MFMA_ONLY_RANDOM_TFLOPS
+            res["roofline"]["frac_of_mfma_only_random"] = round(achieved / MFMA_ONLY_RANDOM_TFLOPS, 4)
         if telemetry:
             res["roofline"].update(telemetry)
             if telemetry.get("sclk_mhz_under_load"):
-                pk = PEAK_BF16_TFLOPS * telemetry["sclk_mhz_under_load"] / 2400.0
+                pk = peak * telemetry["sclk_mhz_under_load"] / 2400.0
                 res["roofline"]["peak_at_measured_clock"] = round(pk, 1)
                 res["roofline"]["frac_at_measured_clock"] = round(achieved / pk, 4)
+        if other:
+            res["config"]["also_select_layer_minus1"] = other
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             res["cpu_baseline"] = cpu_baseline(tok, proj)
         else:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 1
+#define SETOK_ABI_VERSION 2
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -153,11 +153,13 @@ int setok_segment_mean(void* stream, int dtype, const void* h, const int32_t* se
  * Images are consumed in batch order, one per placeholder; a sequence WITHOUT a placeholder still consumes one (:264-271). */
 
 /* Step 1.  seq_len[b] = tokens kept by the mask - placeholders + rows of the sequence's images, truncated to max_length
- * (<= 0: no limit); img_start[b] = index of its first image; status[0] = 1 if the batch needs more than n_images images
- * (the reference raises IndexError at image_features[cur_image_idx]), status[1] = images needed.  attention_mask: uint8
- * (B,T), NULL = all kept (:250-251).  count_ws: int32[2*B] scratch. */
+ * (<= 0: no limit); img_start[b] = index of its first image; status (int32[4]): [0] = 1 if the batch needs more than n_images
+ * images (the reference raises IndexError at image_features[cur_image_idx]), [1] = images needed, [2] = 1 if a kept id other than
+ * the placeholder lies outside [0, vocab) (the reference's embed_tokens raises IndexError, :273; vocab = 0 disables the check),
+ * [3] = flat position b*T + t of the first such id (-1 if none).  attention_mask: uint8 (B,T), NULL = all kept (:250-251).
+ * count_ws: int32[3*B] scratch. */
 int setok_splice_lengths(void* stream, const int64_t* input_ids, const uint8_t* attention_mask, int B, int T,
-                         int64_t image_token_index, const int32_t* img_offsets, int n_images, int max_length,
+                         int64_t image_token_index, int64_t vocab, const int32_t* img_offsets, int n_images, int max_length,
                          int32_t* seq_len, int32_t* img_start, int32_t* status, int32_t* count_ws);
 
 /* Step 2.  For every output position (b, p), p < max_len: src (int32) = embedding-table row (token id) | -(image-token row + 1)

@@ -32,7 +32,7 @@ SIGNATURES = {
     "setok_cluster_sort": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "setok_gather_rows": [_vp, _i, _vp, _vp, _vp, _i, _i],
     "setok_segment_mean": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i],
-    "setok_splice_lengths": [_vp, _vp, _vp, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "setok_splice_lengths": [_vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "setok_splice_plan": [_vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "setok_transpose": [_vp, _i, _vp, _i64, _i, _i, _vp, _i64, _i, _vp],
     "setok_colsum": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i],

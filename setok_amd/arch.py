@@ -14,6 +14,17 @@ IMAGE_TOKEN_INDEX = -200          # src/constants.py:8
 TARGET_TOKEN_INDEX = -300         # src/constants.py:15
 
 
+def config_get(cfg, name: str, default=None):
+    """One accessor for the model config, which callers hand over either as an attribute object (HF `PretrainedConfig`, the
+    reference's case) or as a plain dict (`SetokimLlamaPrefill` accepts both): `getattr` on a dict would silently return the default
+    and drop `tokenizer_model_max_length` / `tokenizer_padding_side` (setokim_arch.py:311-337)."""
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
 @torch.no_grad()
 def encode_images(vision_tower, mm_in_projector, images, **tower_kwargs):
     """image_features, _, _ = vision_tower(images); image_features = mm_in_projector(image_features).
@@ -45,12 +56,17 @@ def splice_multimodal(input_ids, position_ids, attention_mask, labels, image_fea
     ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
     am8 = None if attention_mask is None else attention_mask.to(device=dev).bool().to(torch.uint8).contiguous()     # :252-253
     lab = None if labels is None else labels.to(device=dev, dtype=torch.int64).contiguous()
-    seq_len, img_start, status = ops.splice_lengths(ids, am8, img_offsets, n_images, IMAGE_TOKEN_INDEX, max_length or 0)
+    seq_len, img_start, status = ops.splice_lengths(ids, am8, img_offsets, n_images, IMAGE_TOKEN_INDEX, max_length or 0,
+                                                    vocab=embed_weight.shape[0])
     host = torch.cat([status, seq_len]).cpu()                           # the one synchronisation
     if int(host[0]) != 0:
         raise IndexError(f"the batch needs {int(host[1])} images but only {n_images} were encoded "
                          "(every placeholder, and every sequence without one, consumes an image: setokim_arch.py:264-271,290)")
-    max_len = int(host[2:].max())
+    if int(host[2]) != 0:                                               # the reference's embed_tokens raises here (setokim_arch.py:273)
+        b, t = divmod(int(host[3]), T)
+        raise IndexError(f"index out of range in self: input_ids[{b}, {t}] = {int(input_ids[b, t])} is neither IMAGE_TOKEN_INDEX "
+                         f"({IMAGE_TOKEN_INDEX}) nor a row of the {embed_weight.shape[0]}-row embedding table")
+    max_len = int(host[4:].max())
     src, new_labels, new_mask, new_pos = ops.splice_plan(ids, am8, lab, img_offsets, seq_len, img_start, max_len, padding_side == "left",
                                                          IMAGE_TOKEN_INDEX, IGNORE_INDEX, TARGET_TOKEN_INDEX,
                                                          want_mask=attention_mask is not None, want_pos=position_ids is not None)
@@ -89,5 +105,6 @@ class SetokimVisionMixin:
         cfg = getattr(self, "config", None)
         pos, am, embeds, new_labels = splice_multimodal(
             input_ids, position_ids, attention_mask, labels, image_features, self.get_model().embed_tokens.weight,
-            max_length=getattr(cfg, "tokenizer_model_max_length", None), padding_side=getattr(cfg, "tokenizer_padding_side", "right"))
+            max_length=config_get(cfg, "tokenizer_model_max_length", None),                             # :311-314
+            padding_side=config_get(cfg, "tokenizer_padding_side", "right"))                            # :323
         return None, pos, am, past_key_values, embeds, new_labels

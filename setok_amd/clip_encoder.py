@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._packcache import PackCacheMixin
 
 _VIT_DEFAULTS = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
                      image_size=224, patch_size=14, layer_norm_eps=1e-5, num_channels=3, hidden_act="quick_gelu")
@@ -116,7 +117,7 @@ class ClipVisionParams(nn.Module):
         return self.cfg
 
 
-class CLIPVisionTower(nn.Module):
+class CLIPVisionTower(PackCacheMixin, nn.Module):
     def __init__(self, vision_tower: Optional[Any], unfreeze_mm_vision_tower: Optional[bool] = False,
                  mm_vision_select_feature: Optional[str] = "patch", mm_vision_select_layer: Optional[int] = -2,
                  delay_load=False):
@@ -126,7 +127,7 @@ class CLIPVisionTower(nn.Module):
         self.select_layer = mm_vision_select_layer
         self.select_feature = mm_vision_select_feature
         self.image_processor = None
-        self._packed: Dict[str, Any] = {}
+        self._init_pack_cache()
         if not delay_load or unfreeze_mm_vision_tower:                 # clip_encoder.py:22-27
             self.load_model()
         else:
@@ -162,19 +163,13 @@ class CLIPVisionTower(nn.Module):
         self.vision_tower.load_state_dict(sd, strict=False)
 
     # -- cached compute-ready weights ------------------------------------------------------------
-    def _apply(self, fn, *a, **k):
-        self._packed = {}
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = {}
-        return super().load_state_dict(*a, **k)
-
     def _pack(self):
         """Compute-ready views of the parameters: fused [q;k;v] projection, patch conv as a (C, Kpad)
         GEMM operand, fp32 biases / LayerNorm affine."""
         vt = self.vision_tower
-        key = (vt.dtype, str(vt.device))
+        # one weight per encoder layer + the embeddings: a state-dict load rewrites all of them (and fires the post-hook anyway)
+        key = (vt.dtype, str(vt.device), self._versions([l.mlp.fc1.weight for l in vt.encoder.layers]
+                                                       + [vt.embeddings.patch_embedding.weight, vt.pre_layrnorm.weight]))
         if self._packed.get("key") == key:
             return self._packed
         cfg, dt = vt.cfg, vt.dtype

@@ -329,16 +329,22 @@ __global__ __launch_bounds__(256) void lm_loss_rows_kernel(const T* __restrict__
         if (tid == 0) { loss_row[row] = 0.f; valid_row[row] = 0.f; }
         return;
     }
-    const T* x = logits + (int64_t)row * ld;
-    const int nvec = V / VE;
+    const T* x0 = logits + (int64_t)row * ld;
+    // 16-byte loads need a 16-byte-aligned start: a vocabulary resized for the image tokens (32002, 32003: initialize_vision_tokenizer) gives
+    // contiguous logits rows that start anywhere, so a row is read as [scalar head up to the next 16-byte boundary | vectors | scalar tail]
+    const int head = min(V, (int)(((16u - (unsigned)((size_t)x0 & 15u)) & 15u) / sizeof(T)));
+    const T* x = x0 + head;
+    const int Vb = V - head;
+    const int nvec = Vb / VE;
     float buf[VE];
     float m = -INFINITY;
+    if (tid < head) m = Elem<T>::ld(x0 + tid);
     for (int c = tid; c < nvec; c += 256) {
         ld_vec<T>(x + (int64_t)c * VE, buf);
 #pragma unroll
         for (int i = 0; i < VE; ++i) m = fmaxf(m, buf[i]);
     }
-    for (int c = nvec * VE + tid; c < V; c += 256) m = fmaxf(m, Elem<T>::ld(x + c));
+    for (int c = nvec * VE + tid; c < Vb; c += 256) m = fmaxf(m, Elem<T>::ld(x + c));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -346,19 +352,20 @@ __global__ __launch_bounds__(256) void lm_loss_rows_kernel(const T* __restrict__
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.f;
+    if (tid < head) sum = expf(Elem<T>::ld(x0 + tid) - m);
     for (int c = tid; c < nvec; c += 256) {
         ld_vec<T>(x + (int64_t)c * VE, buf);
 #pragma unroll
         for (int i = 0; i < VE; ++i) sum += expf(buf[i] - m);
     }
-    for (int c = nvec * VE + tid; c < V; c += 256) sum += expf(Elem<T>::ld(x + c) - m);
+    for (int c = nvec * VE + tid; c < Vb; c += 256) sum += expf(Elem<T>::ld(x + c) - m);
     sum = wave_sum(sum);
     if ((tid & 63) == 0) red[tid >> 6] = sum;
     __syncthreads();
     if (tid == 0) {
         const float tot = (red[0] + red[1]) + (red[2] + red[3]);
         const bool in_range = target >= 0 && target < (int64_t)V;
-        loss_row[row] = in_range ? (m + logf(tot)) - Elem<T>::ld(x + target) : NAN;
+        loss_row[row] = in_range ? (m + logf(tot)) - Elem<T>::ld(x0 + target) : NAN;
         valid_row[row] = 1.f;
     }
 }
@@ -462,7 +469,6 @@ extern "C" int setok_lm_loss(void* stream, int dtype, const void* logits, int64_
                              int T, int V, int ignore_index, float* row_ws, float* out) {
     SETOK_CHECK_ARG(logits && labels && row_ws && out, "setok_lm_loss: null operand");
     SETOK_CHECK_ARG(B >= 0 && T > 0 && V > 0 && ld >= V, "setok_lm_loss: bad shape B=%d T=%d V=%d", B, T, V);
-    SETOK_CHECK_ARG(ld % 8 == 0, "setok_lm_loss: the logits row stride must be a multiple of 8 elements");
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * T;
     if (rows > 0) {

@@ -13,34 +13,44 @@ namespace {
 
 constexpr int SRC_PAD = INT32_MIN;
 
-// n_valid[b], n_img[b]
+// n_valid[b], n_img[b], and the position of the sequence's first kept id that the embedding table cannot serve (T = none): a kept id
+// that is not the placeholder must lie in [0, vocab) — the reference's `embed_tokens` raises IndexError otherwise (:273), e.g. for a
+// TARGET_TOKEN_INDEX (-300) that leaked into input_ids; unchecked, a negative id would be decoded as an image-token row by splice_rows.
 __global__ __launch_bounds__(256) void splice_count_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ mask, int T,
-                                                           int64_t image_token, int32_t* __restrict__ cnt) {
-    __shared__ int sv, si;
+                                                           int64_t image_token, int64_t vocab, int B, int32_t* __restrict__ cnt) {
+    __shared__ int sv, si, sbad;
     const int b = blockIdx.x;
-    if (threadIdx.x == 0) { sv = 0; si = 0; }
+    if (threadIdx.x == 0) { sv = 0; si = 0; sbad = T; }
     __syncthreads();
-    int v = 0, im = 0;
+    int v = 0, im = 0, bad = T;
     for (int t = threadIdx.x; t < T; t += 256) {
         const bool keep = mask ? mask[(int64_t)b * T + t] != 0 : true;
-        if (keep) { ++v; im += ids[(int64_t)b * T + t] == image_token; }
+        if (keep) {
+            const int64_t id = ids[(int64_t)b * T + t];
+            ++v; im += id == image_token;
+            if (vocab > 0 && id != image_token && (id < 0 || id >= vocab)) bad = min(bad, t);
+        }
     }
     v = wave_sum_i(v); im = wave_sum_i(im);
     if ((threadIdx.x & 63) == 0) { atomicAdd(&sv, v); atomicAdd(&si, im); }
+    if (bad < T) atomicMin(&sbad, bad);
     __syncthreads();
-    if (threadIdx.x == 0) { cnt[2 * b] = sv; cnt[2 * b + 1] = si; }
+    if (threadIdx.x == 0) { cnt[2 * b] = sv; cnt[2 * b + 1] = si; cnt[2 * B + b] = sbad; }
 }
 
 // One workgroup: img_start[b] = sum_{b' < b} max(n_img[b'], 1)  (a sequence without a placeholder still consumes an index,
 // setokim_arch.py:264-271), new length = kept - placeholders + rows of its images, truncated (:311-314).
 __global__ __launch_bounds__(256) void splice_len_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ img_offsets,
-                                                         int n_images, int B, int max_length, int32_t* __restrict__ seq_len,
+                                                         int n_images, int B, int T, int max_length, int32_t* __restrict__ seq_len,
                                                          int32_t* __restrict__ img_start, int32_t* __restrict__ status) {
     __shared__ int part[256];
+    __shared__ int first_bad;
     const int tid = threadIdx.x;
     const int per = (B + 255) / 256, lo = tid * per, hi = min(lo + per, B);
     int c = 0;
-    for (int b = lo; b < hi; ++b) c += max(cnt[2 * b + 1], 1);
+    if (tid == 0) first_bad = B;
+    __syncthreads();
+    for (int b = lo; b < hi; ++b) { c += max(cnt[2 * b + 1], 1); if (cnt[2 * B + b] < T) atomicMin(&first_bad, b); }
     part[tid] = c;
     __syncthreads();
     if (tid == 0) {
@@ -48,6 +58,8 @@ __global__ __launch_bounds__(256) void splice_len_kernel(const int32_t* __restri
         for (int t = 0; t < 256; ++t) { const int x = part[t]; part[t] = run; run += x; }
         status[0] = run > n_images ? 1 : 0;                         // the reference would raise IndexError at image_features[cur_image_idx]
         status[1] = run;
+        status[2] = first_bad < B ? 1 : 0;                          // ... and at embed_tokens(id) for an id outside the table
+        status[3] = first_bad < B ? first_bad * T + cnt[2 * B + first_bad] : -1;      // flat position of the first such id
     }
     __syncthreads();
     int s = part[tid];
@@ -158,13 +170,13 @@ __global__ __launch_bounds__(256) void splice_rows_kernel(const int32_t* __restr
 }  // namespace
 
 extern "C" int setok_splice_lengths(void* stream, const int64_t* input_ids, const uint8_t* attention_mask, int B, int T,
-                                    int64_t image_token_index, const int32_t* img_offsets, int n_images, int max_length,
+                                    int64_t image_token_index, int64_t vocab, const int32_t* img_offsets, int n_images, int max_length,
                                     int32_t* seq_len, int32_t* img_start, int32_t* status, int32_t* count_ws) {
     SETOK_CHECK_ARG(input_ids && img_offsets && seq_len && img_start && status && count_ws, "setok_splice_lengths: null operand");
-    SETOK_CHECK_ARG(B > 0 && T > 0 && n_images >= 0, "setok_splice_lengths: bad shape B=%d T=%d n_images=%d", B, T, n_images);
+    SETOK_CHECK_ARG(B > 0 && T > 0 && n_images >= 0 && vocab >= 0, "setok_splice_lengths: bad shape B=%d T=%d n_images=%d", B, T, n_images);
     hipStream_t s = (hipStream_t)stream;
-    splice_count_kernel<<<B, 256, 0, s>>>(input_ids, attention_mask, T, image_token_index, count_ws);
-    splice_len_kernel<<<1, 256, 0, s>>>(count_ws, img_offsets, n_images, B, max_length, seq_len, img_start, status);
+    splice_count_kernel<<<B, 256, 0, s>>>(input_ids, attention_mask, T, image_token_index, vocab, B, count_ws);
+    splice_len_kernel<<<1, 256, 0, s>>>(count_ws, img_offsets, n_images, B, T, max_length, seq_len, img_start, status);
     SETOK_CHECK_LAUNCH("setok_splice_lengths");
     return SETOK_OK;
 }

@@ -34,6 +34,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._packcache import PackCacheMixin
 from .tokenizer import PositionalEncoding2D, RaggedTokens
 
 # bert-base-uncased's published config.json (detokenizer.py:27,80 fetches it from the hub; there is no network here and the
@@ -170,7 +171,7 @@ def _resolve_mapper_config(path_or_name: Union[str, Dict[str, Any], None]) -> Di
 
 
 # ----------------------------------------------------------------------------------------------
-class SetokDeTokenizer(nn.Module):
+class SetokDeTokenizer(PackCacheMixin, nn.Module):
     def __init__(self,
                  token_feat_dim: Optional[int] = 4096,
                  hidden_dim: Optional[int] = 4096,
@@ -224,7 +225,7 @@ class SetokDeTokenizer(nn.Module):
                                             for _ in range(decoder_depth)])
         self.initialize_weights()                                                  # before the mapper exists, as in the reference (:53-54)
         self.mapper = BertModel(cfg)
-        self._packed: Dict[str, Any] = {}
+        self._init_pack_cache()
 
     # detokenizer.py:56-69
     def initialize_weights(self):
@@ -252,14 +253,10 @@ class SetokDeTokenizer(nn.Module):
     def device(self):
         return self.mapper_fc_in.weight.device
 
-    def _apply(self, fn, *a, **k):
-        self._packed = {}
-        return super()._apply(fn, *a, **k)
-
     # -- weight packing: fused q|k|v (self) and k|v (cross) projections, fp32 biases / LayerNorm affine ------------------
     def _pack(self):
         w = self.mapper_fc_in.weight
-        key = (w.dtype, str(w.device), w._version, self.mask_tokens._version)
+        key = (w.dtype, str(w.device), self._versions(self.parameters()))
         if self._packed.get("key") == key:
             return self._packed
         lin = lambda m: (m.weight.detach().contiguous(), _f32(m.bias))

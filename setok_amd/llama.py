@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .arch import SetokimVisionMixin
+from ._packcache import PackCacheMixin
+from .arch import SetokimVisionMixin, config_get
 
 
 class _RMSNorm(nn.Module):
@@ -58,7 +59,7 @@ class _DecoderLayer(nn.Module):
         self.post_attention_layernorm = _RMSNorm(D, eps)
 
 
-class LlamaModel(nn.Module):
+class LlamaModel(PackCacheMixin, nn.Module):
     """Parameter container with HF LlamaModel's tree + the prefill on the HIP library."""
 
     def __init__(self, vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, num_key_value_heads, rms_norm_eps,
@@ -71,15 +72,11 @@ class LlamaModel(nn.Module):
         self.layers = nn.ModuleList([_DecoderLayer(hidden_size, num_attention_heads, num_key_value_heads, intermediate_size, rms_norm_eps)
                                      for _ in range(num_hidden_layers)])
         self.norm = _RMSNorm(hidden_size, rms_norm_eps)
-        self._packed: Dict[str, Any] = {}
-
-    def _apply(self, fn, *a, **k):
-        self._packed = {}
-        return super()._apply(fn, *a, **k)
+        self._init_pack_cache()
 
     def _pack(self):
         w = self.norm.weight
-        key = (w.dtype, str(w.device), w._version)
+        key = (w.dtype, str(w.device), self._versions([w] + [l.mlp.down_proj.weight for l in self.layers]))
         if self._packed.get("key") == key:
             return self._packed
         f32 = lambda t: t.detach().float().contiguous()
@@ -128,7 +125,7 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
 
     def __init__(self, config: Any, vision_tower=None, mm_in_projector=None):
         super().__init__()
-        g = (lambda k, d=None: config.get(k, d)) if isinstance(config, dict) else (lambda k, d=None: getattr(config, k, d))
+        g = lambda k, d=None: config_get(config, k, d)
         self.config = config
         self.model = LlamaModel(g("vocab_size"), g("hidden_size"), g("intermediate_size"), g("num_hidden_layers"), g("num_attention_heads"),
                                 g("num_key_value_heads", g("num_attention_heads")), g("rms_norm_eps", 1e-5), g("rope_theta", 10000.0))
@@ -152,7 +149,8 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
             _, position_ids, attention_mask, _, inputs_embeds, new_labels = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, None, labels, comp_images)
             if inputs_embeds is None:                                              # no images: plain text
-                inputs_embeds = self.model.embed_tokens(input_ids)
+                w_e = self.model.embed_tokens.weight.detach().contiguous()
+                inputs_embeds = ops.splice_rows(input_ids.to(device=w_e.device, dtype=torch.int32).contiguous(), w_e, None)
         hidden = self.model(inputs_embeds, attention_mask, position_ids)           # setokim_llama.py:130-140
         B, T, D = hidden.shape
         w = self.lm_head.weight.detach().contiguous()

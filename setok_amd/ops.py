@@ -70,7 +70,7 @@ def profile_stop():
     global _PROFILE
     rec, _PROFILE = _PROFILE or [], None
     torch.cuda.synchronize()
-    return [dict(kernel=k, flops=f, ms=e0.elapsed_time(e1)) for k, f, e0, e1 in rec]
+    return [dict(kernel=k, flops=f, ms=e0.elapsed_time(e1), bytes=b) for k, f, e0, e1, b in rec]
 
 
 def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
@@ -92,7 +92,10 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Option
               _p(out), N, M, N, K, act, 1, 0, 0, 0)
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K, e0, e1))
+        # class = activation + residual (one kernel instantiation each); algorithmic bytes = A, W (+ residual) read once, C written once
+        alg = (M * K + N * K) * a.element_size() + M * N * out.element_size() * (2 if residual is not None else 1)
+        _PROFILE.append((("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32") + ":" + ("plain", "quick_gelu", "gelu_erf")[act]
+                         + ("+residual" if residual is not None else ""), 2.0 * M * N * K, e0, e1, float(alg)))
     return out
 
 
@@ -189,7 +192,7 @@ def cluster_dpc_knn(x: Tensor, B: int, N: int, k: int, threshold: float, min_clu
     if _PROFILE is not None:
         e1.record()
         # algorithmic bytes: read x once, write idx_cluster (int64), score (fp32), index_down (int64, <= N)
-        _PROFILE.append(("cluster_dpc_knn", float(B) * (N * Cc * x.element_size() + N * 8 + N * 4 + N * 8), e0, e1))
+        _PROFILE.append(("cluster_dpc_knn", float(B) * (N * Cc * x.element_size() + N * 8 + N * 4 + N * 8), e0, e1, 0.0))
     return idx, score, index_down, counts
 
 
@@ -227,8 +230,8 @@ def activation(x: Tensor, act: int, out: Optional[Tensor] = None) -> Tensor:
 
 # ---- prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355) --------------------------------------------------------
 def splice_lengths(input_ids: Tensor, attention_mask: Optional[Tensor], img_offsets: Tensor, n_images: int, image_token_index: int,
-                   max_length: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Returns (seq_len int32 (B,), img_start int32 (B,), status int32 (2,)) on the device; no host synchronisation."""
+                   max_length: int, vocab: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
+    """Returns (seq_len int32 (B,), img_start int32 (B,), status int32 (4,)) on the device; no host synchronisation."""
     B, T = input_ids.shape
     dev = input_ids.device
     assert input_ids.dtype == torch.int64 and img_offsets.dtype == torch.int32 and img_offsets.numel() >= n_images + 1
@@ -236,9 +239,9 @@ def splice_lengths(input_ids: Tensor, attention_mask: Optional[Tensor], img_offs
         assert attention_mask.dtype == torch.uint8 and attention_mask.shape == (B, T)
     seq_len = torch.empty((B,), dtype=torch.int32, device=dev)
     img_start = torch.empty((B,), dtype=torch.int32, device=dev)
-    status = torch.empty((2,), dtype=torch.int32, device=dev)
-    ws = torch.empty((2 * B,), dtype=torch.int32, device=dev)
-    _lib.call("setok_splice_lengths", _stream(), _p(input_ids), _p(attention_mask), B, T, image_token_index, _p(img_offsets), n_images,
+    status = torch.empty((4,), dtype=torch.int32, device=dev)
+    ws = torch.empty((3 * B,), dtype=torch.int32, device=dev)
+    _lib.call("setok_splice_lengths", _stream(), _p(input_ids), _p(attention_mask), B, T, image_token_index, int(vocab), _p(img_offsets), n_images,
               int(max_length), _p(seq_len), _p(img_start), _p(status), _p(ws))
     return seq_len, img_start, status
 

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._packcache import PackCacheMixin
 from .clip_encoder import CLIPVisionTower
 
 
@@ -50,7 +51,7 @@ class Attention(nn.Module):                             # module.py:48-73
         self.proj = nn.Linear(dim, dim)
 
 
-class Block(nn.Module):
+class Block(PackCacheMixin, nn.Module):
     """module.py:76-100: `depth` attention sub-layers sharing ONE norm1, then ONE norm2 + Mlp.
     Eval-mode semantics (dropouts are identity; drop_path must be 0)."""
 
@@ -71,15 +72,11 @@ class Block(nn.Module):
                                              Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale),
                                              self.drop_path))
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=proj_drop)
-        self._packed: Dict[str, Any] = {}
-
-    def _apply(self, fn, *a, **k):
-        self._packed = {}
-        return super()._apply(fn, *a, **k)
+        self._init_pack_cache()
 
     def _pack(self):
         w = self.mlp.fc1.weight
-        key = (w.dtype, str(w.device), w._version)
+        key = (w.dtype, str(w.device), self._versions(self.parameters()))
         if self._packed.get("key") == key:
             return self._packed
         f32 = lambda t: None if t is None else t.detach().float().contiguous()

@@ -177,6 +177,8 @@ class HeadTrainer:
         self.grads: Dict[str, torch.Tensor] = {}
         self._comm_stream = None
         self._pending: List = []
+        self._comm_bytes = 0                                            # gradient bytes handed to the all-reduce in the current step
+        self._wait_events: List = []                                    # (before, after) events around step()'s wait for the all-reduce
 
     # -- data-parallel plumbing --------------------------------------------------------------------------------------------
     @property
@@ -192,6 +194,7 @@ class HeadTrainer:
         import torch.distributed as dist
         from .parallel import allreduce_gradients
         names = sorted(g)
+        self._comm_bytes += sum(g[n].numel() * g[n].element_size() for n in names)
         if g[names[0]].is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
@@ -215,13 +218,19 @@ class HeadTrainer:
     @torch.no_grad()
     def backward(self, ctx, dtokens: torch.Tensor) -> Dict[str, torch.Tensor]:
         self._pending = []
+        self._comm_bytes = 0
         self.grads = head_backward(self.tok, ctx, dtokens, on_module_done=self._allreduce_module)
         return self.grads
 
     @torch.no_grad()
     def step(self) -> None:
-        for ev in self._pending:
-            torch.cuda.current_stream().wait_event(ev)
+        if self._pending:                                             # exposed all-reduce time = how long the compute stream stalls here
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for ev in self._pending:
+                torch.cuda.current_stream().wait_event(ev)
+            e1.record()
+            self._wait_events = (self._wait_events + [(e0, e1)])[-64:]
         self._pending = []
         self.t += 1
         scale = 1.0 / self.world                                      # mean over the data-parallel ranks
@@ -230,3 +239,12 @@ class HeadTrainer:
                       self.betas[0], self.betas[1], self.eps, self.wd, self.t, scale)
         self.tok.inner_encoder._packed = {}                          # the packed fp32 biases / LayerNorm affines are copies: re-read them
         self.tok.inter_encoder._packed = {}
+
+    def comm_stats(self) -> Dict[str, float]:
+        """Of the last step(s): gradient bytes all-reduced per step and the exposed (not overlapped with the backward pass) all-reduce time —
+        the compute stream's stall at the top of step().  Synchronises."""
+        ms = 0.0
+        if self._wait_events:
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in self._wait_events) / len(self._wait_events)
+        return dict(allreduce_bytes_per_step=int(self._comm_bytes), exposed_allreduce_ms=round(ms, 4), world=self.world)

@@ -121,3 +121,39 @@ def test_adapter_checkpoint_round_trip(tmp_path):
     res = C.load_pretrained_projector(p, path)
     assert res.missing_keys == [] and res.unexpected_keys == []
     assert all(torch.equal(x, y) for x, y in zip(p.parameters(), m.model.mm_in_projector.parameters()))
+
+
+def test_packed_weight_caches_are_dropped_by_loads_through_a_parent_module():
+    """The compute-ready copies (fused q|k|v, fp32 biases) of the tower, the Blocks and the LLM must not survive a state-dict load that
+    arrives through a PARENT module (`SetokTokenizer.load_state_dict`, `load_pretrained_tokenizer`): nn.Module recurses with
+    `_load_from_state_dict`, so a child's own `load_state_dict` override never runs.  Also in-place updates (optimiser step)."""
+    tok = _small_tok(0)
+    tower, blk = tok.image_feature_encoder, tok.inner_encoder
+    pk_t, pk_b = tower._pack(), blk._pack()
+    assert tower._packed and blk._packed
+    w_before = pk_t["layers"][0]["wqkv"].clone()
+    sd = {k: (v + 1.0 if v.is_floating_point() else v) for k, v in tok.state_dict().items()}
+    tok.load_state_dict(sd)                                        # through the parent
+    assert not tower._packed and not blk._packed
+    assert torch.equal(tower._pack()["layers"][0]["wqkv"], w_before + 1.0)
+    assert torch.equal(blk._pack()["b1"], tok.inner_encoder.mlp.fc1.bias.detach().float())
+    # in-place update of ONE tensor that is not the tensor the old key looked at
+    k0 = blk._pack()["key"]
+    with torch.no_grad():
+        blk.norm2.bias.add_(1.0)
+    assert blk._pack()["key"] != k0 and torch.equal(blk._pack()["n2"][1], blk.norm2.bias.detach().float())
+    from setok_amd.llama import SetokimLlamaPrefill
+    kw = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100)
+    m = SetokimLlamaPrefill(kw)
+    m.model._pack()
+    assert m.model._packed
+    m.load_state_dict({k: v * 2 for k, v in m.state_dict().items()})
+    assert not m.model._packed
+    assert torch.equal(m.model._pack()["layers"][1]["wd"], m.model.layers[1].mlp.down_proj.weight.detach())
+
+
+def test_config_get_reads_dicts_and_attribute_objects():
+    from setok_amd.arch import config_get
+    assert config_get(dict(tokenizer_padding_side="left"), "tokenizer_padding_side", "right") == "left"
+    assert config_get(type("C", (), dict(tokenizer_model_max_length=7))(), "tokenizer_model_max_length") == 7
+    assert config_get(None, "x", 3) == 3 and config_get({}, "x", 4) == 4

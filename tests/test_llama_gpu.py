@@ -180,3 +180,25 @@ def test_prefill_returns_the_lm_loss():
     assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
     with pytest.raises(ValueError):
         m(inputs_embeds=x, attention_mask=am.to(DEV), return_loss=True)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [97, 99, 32003 // 100])
+def test_lm_loss_resized_vocabulary_contiguous_rows(dt, V):
+    """`initialize_vision_tokenizer` resizes the vocabulary when it adds the image tokens (32002, 32003, ...): contiguous logits rows then start
+    at addresses that are not multiples of 16 bytes.  The kernel reads such rows as scalar head | 16-byte vectors | scalar tail."""
+    B, T = 3, 9
+    g = torch.Generator().manual_seed(V)
+    logits = (torch.randn(B, T, V, generator=g) * 3).bfloat16().float()
+    labels = torch.randint(0, V, (B, T), generator=g); labels[:, :2] = -100
+    am = torch.ones(B, T, dtype=torch.long); am[2, 6:] = 0
+    ref = float(O.lm_loss(logits, labels, am))
+    dev_logits = logits.to(dt).to(DEV).contiguous()
+    assert dev_logits.stride(1) == V
+    out = ops.lm_loss(dev_logits, labels.to(DEV), am.to(DEV)).cpu()
+    assert abs(float(out[0]) - ref) <= 2e-6 * abs(ref) + 1e-6
+    # a view that starts one element into an allocation (misaligned base as well as misaligned stride)
+    flat = torch.zeros(B * T * V + 1, dtype=dt, device=DEV)
+    flat[1:] = dev_logits.reshape(-1)
+    out2 = ops.lm_loss(flat[1:].view(B, T, V), labels.to(DEV), am.to(DEV)).cpu()
+    assert abs(float(out2[0]) - ref) <= 2e-6 * abs(ref) + 1e-6

@@ -55,11 +55,13 @@ def _worker(rank, world, port, q):
         #     over ranks (HeadTrainer divides by the world size inside AdamW), through the trainer's own hook
         from setok_amd.training import HeadTrainer
         tr = HeadTrainer.__new__(HeadTrainer)
-        tr.group, tr.bucket_bytes, tr._comm_stream, tr._pending = None, 4096, None, []
+        tr.group, tr.bucket_bytes, tr._comm_stream, tr._pending, tr._comm_bytes, tr._wait_events = None, 4096, None, [], 0, []
         gmod = {"out.weight": torch.full((300, 7), float(rank + 1)), "out.bias": torch.full((300,), 10.0 * (rank + 1))}
         tr._allreduce_module("out", gmod)
         assert torch.allclose(gmod["out.weight"], torch.full((300, 7), 3.0)) and torch.allclose(gmod["out.bias"], torch.full((300,), 30.0))
         assert tr.world == world
+        st = tr.comm_stats()
+        assert st["allreduce_bytes_per_step"] == (300 * 7 + 300) * 4 and st["exposed_allreduce_ms"] == 0.0 and st["world"] == world
         # 4. timing rule
         assert P.max_over_ranks(1.0 + rank) == float(world)
         q.put((rank, "ok"))
@@ -87,3 +89,23 @@ def test_shard_range_edge_cases():
     assert [P.shard_range(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     assert P.shard_range(256, 3, 8) == (96, 128)
     assert P.max_over_ranks(0.5) == 0.5          # not initialised -> identity
+
+
+def test_bench_launches_n_ranks_by_itself():
+    """`python bench.py --gpus N` without a launcher must become N ranks (torch.distributed.run on 127.0.0.1) and report `n_gpus: N` with one
+    record per rank — the driver's SCALE command shape.  `--launch-check` runs the launcher and the rank bookkeeping on CPU over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and sorted(x["rank"] for x in d["ranks"]) == [0, 1]
+    assert abs(d["slowest_seconds"] - 0.02) < 1e-9                      # MAX over the ranks
+    # the launcher and the flag must agree: WORLD_SIZE=1 with --gpus 2 is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode != 0 and "disagree" in r.stderr

@@ -99,3 +99,58 @@ def test_splice_errors_and_passthrough():
     one = ids[:, :1].to(DEV)
     assert h.prepare_inputs_labels_for_multimodal(one, None, None, "pkv", None, torch.zeros(1))[0] is one
     assert h.prepare_inputs_labels_for_multimodal(ids.to(DEV), None, None, None, None, None)[4] is None
+
+
+@pytest.mark.parametrize("as_dict", [True, False])
+def test_mixin_honours_truncation_and_left_padding_for_dict_and_attribute_configs(golden_dir, as_dict):
+    """setokim_arch.py:304-337: `tokenizer_model_max_length` and `tokenizer_padding_side` come from `self.config`, which hosts hand over
+    as an attribute object (HF) or as a plain dict (SetokimLlamaPrefill accepts both); the outputs must equal the reference's own
+    golden outputs of the truncated, left-padded case either way."""
+    name = "trunc_left"
+    z, ids, am, labels, feats, W, kw = _case(golden_dir, name)
+    assert kw["padding_side"] == "left" and kw["max_length"] is not None
+    cfg = dict(tokenizer_model_max_length=kw["max_length"], tokenizer_padding_side="left")
+
+    class Emb:
+        weight = W.to(DEV)
+
+    class M:
+        embed_tokens = Emb()
+
+    class Host(setok_amd.SetokimVisionMixin):
+        vision_tower = object()
+        mm_in_projector = None
+        config = cfg if as_dict else type("Cfg", (), cfg)()
+
+        def get_model(self):
+            return M()
+
+        def encode_images(self, images, **kw_):
+            return [f.to(DEV) for f in feats]
+
+    T = ids.shape[1]
+    pos = torch.arange(T).expand(ids.shape[0], T).clone()
+    out = Host().prepare_inputs_labels_for_multimodal(ids.to(DEV), pos.to(DEV), am.to(DEV), None, labels.to(DEV), torch.zeros(len(feats), 3, 2, 2))
+    assert torch.equal(out[4].cpu(), _t(z[f"{name}:full:embeds"]))
+    assert torch.equal(out[1].cpu(), _t(z[f"{name}:full:pos"])) and torch.equal(out[2].cpu(), _t(z[f"{name}:full:mask"]))
+    assert torch.equal(out[5].cpu(), _t(z[f"{name}:full:labels"]))
+    assert out[4].shape[1] <= kw["max_length"]
+
+
+def test_ids_outside_the_embedding_table_raise_like_embed_tokens():
+    """The reference embeds every kept non-placeholder id with `embed_tokens` (setokim_arch.py:273), which raises IndexError for a negative id
+    (e.g. a TARGET_TOKEN_INDEX = -300 that leaked into input_ids) or one >= vocab; masked-out positions are never embedded (:258-259)."""
+    ids, am, labels, feats, W = O.splice_inputs(7, 4, 10, 30, 8)
+    fd = [f.to(DEV) for f in feats]
+    kept = [(b, t) for b in range(ids.shape[0]) for t in range(ids.shape[1]) if am[b, t] and ids[b, t] != O.IMAGE_TOKEN_INDEX]
+    dropped = [(b, t) for b in range(ids.shape[0]) for t in range(ids.shape[1]) if not am[b, t]]
+    b, t = kept[len(kept) // 2]
+    for bad in (O.TARGET_TOKEN_INDEX, -1, W.shape[0], W.shape[0] + 5):
+        bad_ids = ids.clone(); bad_ids[b, t] = bad
+        with pytest.raises(IndexError, match=rf"input_ids\[{b}, {t}\]"):
+            setok_amd.splice_multimodal(bad_ids.to(DEV), None, am.to(DEV), labels.to(DEV), fd, W.to(DEV))
+    if dropped:                                                          # an out-of-table id under the mask is harmless, as in the reference
+        ok_ids = ids.clone(); ok_ids[dropped[0]] = W.shape[0] + 7
+        got = setok_amd.splice_multimodal(ok_ids.to(DEV), None, am.to(DEV), labels.to(DEV), fd, W.to(DEV))
+        ref = O.splice_multimodal(ids, None, am, labels, feats, W)
+        assert torch.equal(got[2].cpu(), ref[2])

@@ -1,13 +1,23 @@
 #!/usr/bin/env python
-"""HBM traffic per launch of the dominant GEMM kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of the same
-command:  python tools/gemm_traffic.py <fetch.db> <write.db> > profiles/rNN_gemm_traffic.json
+"""HBM traffic per launch of the GEMM kernels (per instantiation) and of the clustering call, from two rocprofv3 PMC passes
+(FETCH_SIZE, WRITE_SIZE: separate passes, kernel-trace only) of the same command:
 
-Units and the gfx950 correction follow MI355X_MICROARCH.md's HBM/rocprofv3 section: both counters are in KiB; FETCH_SIZE
-under-reports 16-byte-per-lane streams by 2x on gfx950 — calibrated in the SAME run on layernorm_kernel, whose traffic is known
-exactly (reads rows*C*2 bytes, writes the same)."""
+    python tools/gemm_traffic.py <fetch.db> <write.db> > profiles/rNN_traffic.json
+
+Units and the gfx950 correction follow MI355X_MICROARCH.md's HBM / rocprofv3 section: both counters are in KiB; FETCH_SIZE
+under-reports 16-byte-per-lane streams by 2x on gfx950.  The factor is CALIBRATED in the same run on a kernel whose traffic is known
+exactly and whose access width is the same (16 B per lane): a row-wise pass that reads and writes the same number of bytes
+(`layernorm_rows_kernel`, else `gather_rows_kernel`), so WRITE_SIZE / FETCH_SIZE of that kernel IS the factor.  The script fails loudly
+when a kernel it needs is not in the databases — a renamed kernel must never turn into an empty artefact."""
 import json
+import re
 import sqlite3
 import sys
+
+KIB = 1024.0
+CLUSTER_KERNELS = ("dpc_",)                    # every kernel of setok_cluster_dpc_knn (csrc/cluster.hip) carries this prefix
+CALIBRATION_KERNELS = ("layernorm_rows_kernel", "gather_rows_kernel")
+ACT = {"0": "plain", "1": "quick_gelu", "2": "gelu_erf"}
 
 
 def per_kernel(db, counter):
@@ -18,25 +28,87 @@ def per_kernel(db, counter):
             continue
         name = str(name).replace("(anonymous namespace)::", "")
         agg.setdefault(name, []).append(float(v))
+    if not agg:
+        sys.exit(f"{db}: no {counter} samples")
     return agg
 
 
-fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-pick = lambda d, sub: [v for k, vs in d.items() if sub in k for v in vs]
-gf, gw = pick(fetch, "gemm_persist_kernel"), pick(write, "gemm_persist_kernel")
-lf, lw = pick(fetch, "layernorm_kernel"), pick(write, "layernorm_kernel")
-KIB = 1024.0
-# calibration: the ViT-tower LayerNorm launches (the largest ones) move exactly rows * C * 2 bytes each way
-ln_f, ln_w = max(lf) * KIB, max(lw) * KIB
-corr = round(ln_w / ln_f) if ln_f > 0 else 1          # WRITE_SIZE is exact for this stream, so the ratio is FETCH's factor
-raw_f, raw_w = sum(gf) / len(gf) * KIB, sum(gw) / len(gw) * KIB
-print(json.dumps({
-    "kernel": "gemm_persist_kernel<*>", "launches": len(gf),
-    "fetch_size_raw_bytes": int(raw_f), "write_size_raw_bytes": int(raw_w), "fetch_correction": float(corr),
-    "calibration": f"layernorm_kernel, same run: FETCH_SIZE {ln_f / 1e6:.1f} MB vs WRITE_SIZE {ln_w / 1e6:.1f} MB for a stream that reads and "
-                   f"writes the same number of bytes (16 B per lane) -> x{corr}",
-    "traffic_bytes_per_launch": int(raw_f * corr + raw_w),
-    "algorithmic_bytes_per_launch_note": "QKV 545 MB, proj 406 MB, fc1 682 MB, fc2 817 MB (A + W [+ residual] read once, C written once); "
-                                         "launch-weighted mean over the step's GEMMs ~ 640 MB",
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline",
-}, indent=1))
+def pick(d, sub):
+    return {k: vs for k, vs in d.items() if sub in k}
+
+
+def need(d, sub, what):
+    got = pick(d, sub)
+    if not got:
+        sys.exit(f"gemm_traffic.py: no kernel matching '{sub}' in the {what} pass; kernels seen: {sorted(d)[:40]}")
+    return got
+
+
+def gemm_class(name):
+    m = re.search(r"gemm_persist_kernel<\s*(\d+)\s*,\s*(\w+)\s*(?:,\s*(\w+)\s*)?>", name)
+    if not m:
+        return name
+    act, f32b, resk = m.group(1), m.group(2), m.group(3) or "false"
+    if f32b in ("true", "1"):
+        return "fp32_batched"
+    return ACT.get(act, act) + ("+residual" if resk in ("true", "1") else "")
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    # ---- calibration ----------------------------------------------------------------------------------------------------------------
+    cal = None
+    for name in CALIBRATION_KERNELS:
+        f, w = pick(fetch, name), pick(write, name)
+        if f and w:
+            lf = max(v for vs in f.values() for v in vs) * KIB           # the largest launches (the ViT-sized ones): rows * C * 2 bytes each way
+            lw = max(v for vs in w.values() for v in vs) * KIB
+            cal = (name, lf, lw)
+            break
+    if cal is None:
+        sys.exit(f"gemm_traffic.py: none of the calibration kernels {CALIBRATION_KERNELS} is in both passes; kernels seen: {sorted(fetch)[:40]}")
+    corr = float(round(cal[2] / cal[1])) if cal[1] > 0 else 1.0
+    if corr not in (1.0, 2.0):
+        sys.exit(f"gemm_traffic.py: implausible FETCH_SIZE factor {cal[2] / cal[1]:.3f} from {cal[0]}")
+
+    # ---- GEMM, per instantiation --------------------------------------------------------------------------------------------------------
+    gf, gw = need(fetch, "gemm_persist_kernel", "FETCH_SIZE"), need(write, "gemm_persist_kernel", "WRITE_SIZE")
+    per_class, tot_f, tot_w, tot_n = {}, 0.0, 0.0, 0
+    for name in sorted(gf):
+        if name not in gw:
+            sys.exit(f"gemm_traffic.py: {name} is in the FETCH_SIZE pass but not in the WRITE_SIZE pass")
+        f, w = gf[name], gw[name]
+        if len(f) != len(w):
+            sys.exit(f"gemm_traffic.py: {name}: {len(f)} launches in the FETCH_SIZE pass, {len(w)} in the WRITE_SIZE pass (not the same command?)")
+        rf, rw = sum(f) / len(f) * KIB, sum(w) / len(w) * KIB
+        per_class[gemm_class(name)] = {"launches": len(f), "fetch_size_raw_bytes": int(rf), "write_size_raw_bytes": int(rw),
+                                       "traffic_bytes_per_launch": int(rf * corr + rw)}
+        tot_f += sum(f) * KIB; tot_w += sum(w) * KIB; tot_n += len(f)
+
+    # ---- clustering: all kernels of one setok_cluster_dpc_knn call ------------------------------------------------------------------------
+    cl, calls = {}, None
+    for sub in CLUSTER_KERNELS:
+        cf, cw = need(fetch, sub, "FETCH_SIZE"), need(write, sub, "WRITE_SIZE")
+        for name in sorted(cf):
+            f, w = cf[name], cw.get(name)
+            if w is None or len(w) != len(f):
+                sys.exit(f"gemm_traffic.py: {name}: launch counts differ between the passes")
+            short = re.sub(r"\(.*", "", name).replace("void ", "")
+            cl[short] = {"launches": len(f), "traffic_bytes_per_launch": int(sum(f) / len(f) * KIB * corr + sum(w) / len(w) * KIB)}
+            calls = len(f) if calls is None else min(calls, len(f))
+    cl_total = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in cl.values()) / max(calls or 1, 1)
+
+    print(json.dumps({
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline",
+        "fetch_correction": corr,
+        "calibration": f"{cal[0]}, same run: FETCH_SIZE {cal[1] / 1e6:.1f} MB vs WRITE_SIZE {cal[2] / 1e6:.1f} MB for a stream that reads and writes the "
+                       f"same number of bytes (16 B per lane) -> x{corr:g}",
+        "gemm": {"kernel": "gemm_persist_kernel<*>", "launches": tot_n, "traffic_bytes_per_launch": int((tot_f * corr + tot_w) / tot_n),
+                 "per_class": per_class},
+        "clustering": {"kernels": cl, "calls": calls, "traffic_bytes_per_launch": int(cl_total),
+                       "note": "bytes of ALL kernels of one setok_cluster_dpc_knn call (256 images)"},
+    }, indent=1))
+
+
+if __name__ == "__main__":
+    main()

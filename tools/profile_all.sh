@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on the GPU box: bash tools/profile_all.sh r01   (≈10 GPU-minutes)
-tag=${1:-r01}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT

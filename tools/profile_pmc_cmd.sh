@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC-derived metrics of one command's kernels (one pass per metric, kernel-trace only): tools/profile_pmc_cmd.sh <tag> "<metrics>" <cmd...>
 tag=$1; metrics=$2; shift; shift
-out=$GRAFT_REPO_ROOT/gpurun_out/r01
+out=$GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r02}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for m in $metrics; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace summary of the bench + the two PMC passes for HBM traffic.
-# usage (through gpurun): bash tools/profile_round.sh r01
-tag=${1:-r01}
+# usage (through gpurun): bash tools/profile_round.sh r02
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -13,5 +13,5 @@ python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/pk -name "*.db" | head 
 F=$(find /tmp/pf -name "*.db" | head -1); W=$(find /tmp/pw -name "*.db" | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $F > $out/bench_pmc_FETCH_SIZE.txt
 python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $W > $out/bench_pmc_WRITE_SIZE.txt
-python $GRAFT_REPO_ROOT/tools/gemm_traffic.py $F $W > $out/gemm_traffic.json
-head -24 $out/bench_kernel_stats.csv; cat $out/gemm_traffic.json; tail -2 $out/bench_under_rocprof.log
+python $GRAFT_REPO_ROOT/tools/gemm_traffic.py $F $W > $out/traffic.json || { echo "gemm_traffic.py FAILED"; rm -f $out/traffic.json; }
+head -24 $out/bench_kernel_stats.csv; cat $out/traffic.json; tail -2 $out/bench_under_rocprof.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # MFMA / LDS utilisation of the bench's kernels from PMC-derived metrics (separate passes, kernel-trace only): bash tools/profile_util.sh r01
-tag=${1:-r01}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
