@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._packcache import f32_of
 from .detokenizer import SetokDeTokenizer
 from .tokenizer import SetokTokenizer
 
@@ -75,11 +76,10 @@ class VisionProjector(nn.Sequential):
             m = mods[i]
             if isinstance(m, nn.Linear):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU)
-                h = ops.linear(h, m.weight.detach().contiguous(), None if m.bias is None else m.bias.detach().float().contiguous(),
-                               act=ops.ACT_GELU_ERF if fuse else ops.ACT_NONE)
+                h = ops.linear(h, m.weight.detach().contiguous(), f32_of(m, "bias", m.bias), act=ops.ACT_GELU_ERF if fuse else ops.ACT_NONE)
                 i += 2 if fuse else 1
             elif isinstance(m, nn.LayerNorm):
-                h = ops.layernorm(h, m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), m.eps)
+                h = ops.layernorm(h, f32_of(m, "weight", m.weight), f32_of(m, "bias", m.bias), m.eps)
                 i += 1
             elif isinstance(m, nn.GELU):
                 h = ops.activation(h, ops.ACT_GELU_ERF)
@@ -119,8 +119,7 @@ class LinearProjector(nn.Linear):
         if hasattr(x, "map") and hasattr(x, "packed"):
             return x.map(self.forward)
         shape = x.shape
-        h = ops.linear(x.reshape(-1, shape[-1]).contiguous(), self.weight.detach().contiguous(),
-                       self.bias.detach().float().contiguous())
+        h = ops.linear(x.reshape(-1, shape[-1]).contiguous(), self.weight.detach().contiguous(), f32_of(self, "bias", self.bias))
         return h.reshape(*shape[:-1], h.shape[-1])
 
 

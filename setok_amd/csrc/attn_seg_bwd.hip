@@ -269,12 +269,9 @@ __global__ __launch_bounds__(256) void attn_seg_bwd_kv_kernel(const bf16* __rest
 int setok_attention_bwd_seg_bf16(hipStream_t s, const bf16* qkv, const int32_t* seg_offsets, int n_segs, const bf16* out, const bf16* dout,
                                  bf16* dqkv, float* lse_ws, float* d_ws, int H, int Dh, float scale) {
     if (Dh != SD || !seg_offsets || n_segs <= 0) return SETOK_EUNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_seg_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS) != hipSuccess)
-            return setok_fail(SETOK_ELAUNCH, "setok_attention_bwd: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static SetokDeviceOnce once;
+    if (!once.run([] { return hipFuncSetAttribute((const void*)attn_seg_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KV_LDS) == hipSuccess; }))
+        return setok_fail(SETOK_ELAUNCH, "setok_attention_bwd: cannot raise the dynamic LDS limit");
     attn_seg_bwd_q_kernel<<<dim3(n_segs, H), 256, 0, s>>>(qkv, seg_offsets, out, dout, dqkv, lse_ws, d_ws, H, scale);
     attn_seg_bwd_kv_kernel<<<dim3(n_segs, H), 256, KV_LDS, s>>>(qkv, seg_offsets, dout, dqkv, lse_ws, d_ws, H, scale);
     SETOK_CHECK_LAUNCH("setok_attention_bwd(segments bf16)");

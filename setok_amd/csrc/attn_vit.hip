@@ -187,12 +187,9 @@ template <int NW, int DH>
 int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, float scale) {
     const int Tp = (T + 31) & ~31;
     const size_t smem = (size_t)Tp * ROWB * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
-        attr_set = true;
-    }
+    static SetokDeviceOnce once;                   // one per instantiation; per device inside
+    if (!once.run([] { return hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
+        return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
     attn_vit_kernel<NW, false, DH><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
                                                                       0, nullptr, 0, 0);
     SETOK_CHECK_LAUNCH("setok_attention(vit bf16)");
@@ -204,12 +201,9 @@ int launch_cross(hipStream_t s, const bf16* q, int64_t ldq, const bf16* k, const
                  int n_segs, int q_len, int max_kv, bf16* out, int64_t ldo, int H, float scale) {
     const int Tp = (max_kv + 31) & ~31;
     const size_t smem = (size_t)Tp * ROWB * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_vit_kernel<NW, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return setok_fail(SETOK_ELAUNCH, "cross attention: cannot raise dynamic LDS limit");
-        attr_set = true;
-    }
+    static SetokDeviceOnce once;
+    if (!once.run([] { return hipFuncSetAttribute((const void*)attn_vit_kernel<NW, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
+        return setok_fail(SETOK_ELAUNCH, "cross attention: cannot raise dynamic LDS limit");
     attn_vit_kernel<NW, true, 64><<<dim3(H, n_segs), NW * 64, smem, s>>>(q, out, max_kv, H, scale * 1.44269504088896340736f, ldq, k, v, ldkv,
                                                                      kv_offsets, q_len, ldo);
     SETOK_CHECK_LAUNCH("setok_cross_attention(bf16 mfma)");

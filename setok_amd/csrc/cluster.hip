@@ -340,12 +340,9 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
     const float sqrtC = (float)sqrt((double)C);
     if (dtype == SETOK_BF16 && C % GR_K == 0) {
         // Gram matrices + diagonals in one launch (bf16 throughput mode)
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)gram_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GR_STAGE) != hipSuccess)
-                return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot raise the dynamic LDS limit");
-            attr_set = true;
-        }
+        static SetokDeviceOnce once;
+        if (!once.run([] { return hipFuncSetAttribute((const void*)gram_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GR_STAGE) == hipSuccess; }))
+            return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot raise the dynamic LDS limit");
         const int strips = cdiv(N, GR_ROWS), chunks = cdiv(N, GR_COLS);
         gram_bf16_kernel<<<cdiv(B, 8) * 8 * strips * chunks, 256, 2 * GR_STAGE, s>>>((const bf16*)x, dist_ws, vec_ws, B, N, C, strips, chunks);
     } else {

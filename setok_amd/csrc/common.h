@@ -31,6 +31,40 @@ int setok_fail(int code, const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- per-device one-time setup (host) ---------------------------------------------------------
+// hipFuncSetAttribute (dynamic-LDS limit) is a property of (function, DEVICE); a process-wide `static bool` would skip it on a second
+// device of the same process and races between threads.  One atomic bit per device: the setup is idempotent, so two threads doing it at
+// the same time is harmless; nothing else in the library keeps mutable global state.
+struct SetokDeviceOnce {
+    unsigned long long done = 0;            // bit d: done on device d (devices >= 64 redo it on every call)
+    template <class F>
+    bool run(F&& setup) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev >= 0 && dev < 64 && ((__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return true;
+        if (!setup()) return false;
+        if (dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
+        return true;
+    }
+};
+
+// A small per-device cache of one value (device symbol address, CU count): slot d holds device d's value.
+template <class T>
+struct SetokPerDevice {
+    T val[64] = {};
+    unsigned long long have = 0;
+    template <class F>
+    bool get(T& out, F&& query) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const bool slot = dev >= 0 && dev < 64;
+        if (slot && ((__atomic_load_n(&have, __ATOMIC_ACQUIRE) >> dev) & 1ull)) { out = val[dev]; return true; }
+        if (!query(out)) return false;
+        if (slot) { val[dev] = out; __atomic_fetch_or(&have, 1ull << dev, __ATOMIC_RELEASE); }
+        return true;
+    }
+};
+
 // ---- element access templated on the storage type ------------------------------------------
 template <typename T> struct Elem;
 template <> struct Elem<float> {

@@ -519,14 +519,12 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 }
 
 int launch_tail(hipStream_t s, const PArgs& g, int act) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        bool ok = hipFuncSetAttribute((const void*)gemm_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
-        if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static SetokDeviceOnce once;
+    if (!once.run([] {
+            bool ok = hipFuncSetAttribute((const void*)gemm_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+            ok = ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+            return ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess; }))
+        return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
     const int grid = g.tilesM * g.tilesN;
     if (act == SETOK_ACT_NONE) gemm_tail_kernel<0><<<grid, 256, TAIL_LDS, s>>>(g);
     else if (act == SETOK_ACT_QUICK_GELU) gemm_tail_kernel<1><<<grid, 256, TAIL_LDS, s>>>(g);
@@ -536,16 +534,15 @@ int launch_tail(hipStream_t s, const PArgs& g, int act) {
 }
 
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        bool ok = true;
-        const void* fns[] = {(const void*)gemm_persist_kernel<0, false, false>, (const void*)gemm_persist_kernel<1, false, false>,
-                             (const void*)gemm_persist_kernel<2, false, false>, (const void*)gemm_persist_kernel<0, false, true>,
-                             (const void*)gemm_persist_kernel<1, false, true>, (const void*)gemm_persist_kernel<2, false, true>};
-        for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-        if (!ok) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static SetokDeviceOnce once;
+    if (!once.run([] {
+            bool ok = true;
+            const void* fns[] = {(const void*)gemm_persist_kernel<0, false, false>, (const void*)gemm_persist_kernel<1, false, false>,
+                                 (const void*)gemm_persist_kernel<2, false, false>, (const void*)gemm_persist_kernel<0, false, true>,
+                                 (const void*)gemm_persist_kernel<1, false, true>, (const void*)gemm_persist_kernel<2, false, true>};
+            for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+            return ok; }))
+        return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
@@ -556,14 +553,21 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
     return SETOK_OK;
 }
 
-int cu_count() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-        return v;
-    }();
+int cu_count() {                                    // of the CURRENT device
+    static SetokPerDevice<int> cache;
+    int n = 256;
+    cache.get(n, [](int& v) {
+        int dev = 0;
+        return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0;
+    });
     return n;
+}
+
+const float* zero_bias() {                          // the current device's copy of kZeroBias (a __device__ symbol has one address per device)
+    static SetokPerDevice<const float*> cache;
+    const float* p = nullptr;
+    cache.get(p, [](const float*& v) { void* q = nullptr; if (hipGetSymbolAddress(&q, HIP_SYMBOL(kZeroBias)) != hipSuccess) return false; v = (const float*)q; return true; });
+    return p;
 }
 
 }  // namespace
@@ -597,7 +601,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
     PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1};
     if (!bias) {
-        static const float* zb = [] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(kZeroBias)) == hipSuccess ? (const float*)q : nullptr; }();
+        const float* zb = zero_bias();
         if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
         g.zero_bias = zb;
     }
@@ -631,13 +635,10 @@ int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16*
 // gradient.  Same kernel, F32B variant.
 int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
                                    int64_t sA, int64_t sW, int64_t sC) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) != hipSuccess)
-            return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
-    static const float* zb = [] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(kZeroBias)) == hipSuccess ? (const float*)q : nullptr; }();
+    static SetokDeviceOnce once;
+    if (!once.run([] { return hipFuncSetAttribute((const void*)gemm_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess; }))
+        return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
+    const float* zb = zero_bias();
     if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
     const int tilesM = cdiv(M, TM), tilesN = cdiv(N, 256);
     PArgs g{A, W, nullptr, nullptr, nullptr, lda, ldc, M, N, K, tilesM, tilesN, 0, nullptr, zb, C, sA, sW, sC, batch};

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._packcache import PackCacheMixin
+from ._packcache import PackCacheMixin, f32_of
 from .clip_encoder import CLIPVisionTower
 
 
@@ -347,7 +347,7 @@ class SetokTokenizer(nn.Module):
         group = ops.segment_mean(hs, seg_offsets, img_offsets[B:], total)          # :151-153
         stages = dict(x=x, group=group.clone()) if return_stages else None
         inter = self.inter_encoder.forward_rows(group, img_offsets, B, max(counts_h))   # :179 (+D2)
-        tokens = ops.linear(inter, self.out.weight.detach().contiguous(), self.out.bias.detach().float().contiguous())  # :180
+        tokens = ops.linear(inter, self.out.weight.detach().contiguous(), f32_of(self.out, "bias", self.out.bias))      # :180
         out = (RaggedTokens(tokens, counts_h), idx, score.reshape(B, 1, N))
         if return_stages:
             stages.update(index_down=index_down, counts=counts_h, inter=inter)

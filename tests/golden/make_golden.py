@@ -184,6 +184,35 @@ def gen_tower_features_vitl():
         out[f"{i}:fb:tokens_rowsum"] = npy(r["tokens"].double().sum(dim=1))
     save("vitl_224", **out)
 
+def gen_tower_features_vitl336():
+    """BASELINE cfg4 at full size: reference tower + head for ViT-L/14-**336** (576 patches, T = 577), 2 images, same seeds and recipe as
+    vitl_224.  Stores the reference's tower features in full and every downstream output (tokens in full: the dynamic-k threshold yields tens of
+    tokens per image)."""
+    vc = O.VitConfig(image_size=336)
+    hc = O.HeadConfig(threshold=0.125)
+    tsd = O.init_tower_weights(vc, seed=0)
+    hsd = O.init_head_weights(hc, seed=1)
+    d = R.make_clip_dir(vc.hidden_size, vc.num_hidden_layers, vc.num_attention_heads, vc.intermediate_size,
+                        vc.image_size, vc.patch_size, seed=0)
+    tok = R.build_reference_tokenizer(d, hidden_dim=1024, token_feat_dim=4096, dim_feedforward=4096,
+                                      min_cluster_num=64, threshold=0.125, select_layer=-2)
+    full = dict(tsd); full.update(hsd)
+    load_weights_into(tok, full)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(2, 3, 336, 336, generator=g)
+    out = {"spec": np.array([0, 1, 3], dtype=np.int64)}   # tower seed, head seed, image seed
+    feats, res = R.rac_forward(tok, images, noise=None, return_stages=True)
+    out["feats"] = npy(feats)
+    for i, r in enumerate(res):
+        print(f"  vitl336/img{i}: L={r['tokens'].shape[0]} score[{r['score'].min():.4f},{r['score'].max():.4f}]")
+        out[f"{i}:index_down"] = npy(r["index_down"]).astype(np.int32)
+        out[f"{i}:idx_cluster"] = npy(r["idx_cluster"]).astype(np.int32)
+        out[f"{i}:score"] = npy(r["score"])
+        out[f"{i}:group"] = npy(r["group"]).astype(np.float32)
+        out[f"{i}:tokens"] = npy(r["tokens"]).astype(np.float32)
+    save("vitl_336", **out)
+
+
 # ----------------------------------------------------------------------------------------------
 DETOK_CASES = {
     # name: (DetokConfig kwargs, seed, token counts per image)
@@ -317,6 +346,44 @@ def gen_llama():
     save("llama", **arrs)
 
 
+LLAMA_7B_DIMS = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=2, num_attention_heads=32, num_key_value_heads=32, vocab_size=32000)
+LLAMA_7B_CASE = (21, 2, 40, "right")               # seed, B, T, padding
+LOGIT_COL_STRIDE = 61                               # every 61st vocabulary column at every position (+ all 32000 at each sequence's last token)
+
+
+def gen_llama_7bdims():
+    """BASELINE cfg5 at Vicuna-7B layer dims (hidden 4096, 32 heads x 128, SwiGLU 11008, vocab 32000), TWO decoder layers: HuggingFace
+    LlamaForCausalLM (eager attention, fp32) on seeded inputs.  The 0.67 G parameters regenerate from the seed (oracle.init_llama_weights);
+    stored: the final hidden states in full, the logits at every position for every 61st vocabulary column, and all 32000 logits at each
+    sequence's last valid token."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    kw = LLAMA_7B_DIMS
+    seed, B, T, padding = LLAMA_7B_CASE
+    lc = O.LlamaConfigLite(**kw)
+    sd = O.init_llama_weights(lc, seed=seed)
+    cfg = LlamaConfig(**kw, rms_norm_eps=lc.rms_norm_eps, rope_theta=lc.rope_theta, attention_bias=False, mlp_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    with torch.device("meta"):
+        m = LlamaForCausalLM(cfg)
+    m = m.to_empty(device="cpu").eval()
+    m.load_state_dict(sd, strict=True, assign=True)
+    # rotary inv_freq is a non-persistent buffer: to_empty() left it uninitialised -> rebuild it the way HF does
+    inv = 1.0 / (lc.rope_theta ** (torch.arange(0, lc.head_dim, 2, dtype=torch.int64).float() / lc.head_dim))
+    m.model.rotary_emb.inv_freq = inv
+    if hasattr(m.model.rotary_emb, "original_inv_freq"):
+        m.model.rotary_emb.original_inv_freq = inv
+    x, am, pos = O.llama_inputs(lc, seed, B, T, padding)
+    with torch.no_grad():
+        out = m(inputs_embeds=x, attention_mask=am, position_ids=pos, output_hidden_states=True)
+        ref_h, ref_l = O.llama_forward(sd, lc, x, am, pos)
+    print("oracle vs HF at 7B dims: hidden", float((ref_h - out.hidden_states[-1]).abs().max()), "logits", float((ref_l - out.logits).abs().max()))
+    last = [int(am[b].nonzero().max()) for b in range(B)]
+    arrs = {"cfg_keys": np.array(list(kw.keys())), "cfg_vals": np.array(list(kw.values())), "spec": np.array([seed, B, T, 0]),
+            "hidden": npy(out.hidden_states[-1]), "logits_cols": npy(out.logits[:, :, ::LOGIT_COL_STRIDE]),
+            "logits_last": npy(torch.stack([out.logits[b, last[b]] for b in range(B)])), "last": np.array(last)}
+    save("llama_7bdims", **arrs)
+
+
 LM_LOSS_CASES = {"plain": (0, 2, 9, 37, "none"), "right_pad": (1, 3, 12, 50, "right"), "left_pad_ignored": (2, 3, 11, 64, "left")}
 
 
@@ -353,3 +420,7 @@ if __name__ == "__main__":
         gen_e2e_small()
     if "vitl" in which:
         gen_tower_features_vitl()
+    if "vitl336" in which:
+        gen_tower_features_vitl336()
+    if "llama_7bdims" in which:
+        gen_llama_7bdims()

@@ -300,3 +300,49 @@ def test_lm_loss_matches_reference(golden_dir):
         logits, labels, am = O.lm_loss_inputs(seed, B, T, V, str(z[c + ":padding"]))
         got = O.lm_loss(logits, labels, am)
         assert abs(float(got) - float(z[c + ":loss"][0])) <= 1e-6 * abs(float(z[c + ":loss"][0]))
+
+
+def test_vitl336_head_from_reference_features(golden_dir):
+    """BASELINE cfg4 dims (ViT-L/14-336: 576 patches): the oracle's head on the reference's own tower features (identical fp32 input)
+    reproduces the reference's integers exactly and its tensors within fp32 rounding."""
+    z = _load(golden_dir, "vitl_336")
+    hc = O.HeadConfig(threshold=0.125)
+    sd = O.init_head_weights(hc, seed=int(z["spec"][1]))
+    feats = _t(z["feats"])
+    assert tuple(feats.shape) == (2, 576, 1024)
+    for i in range(feats.shape[0]):
+        r = O.head_forward(sd, hc, feats[i])
+        assert torch.equal(r.index_down, _t(z[f"{i}:index_down"]).long())
+        assert torch.equal(r.idx_cluster, _t(z[f"{i}:idx_cluster"]).long())
+        torch.testing.assert_close(r.score, _t(z[f"{i}:score"]), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(r.group, _t(z[f"{i}:group"]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(r.tokens, _t(z[f"{i}:tokens"]), rtol=1e-4, atol=1e-5)
+
+
+def test_vitl336_tower_restatement_close_to_reference(golden_dir):
+    """Third-party boundary at T = 577: restated CLIP ViT-L/14-336 vs the reference's HF tower (seeded weights), one image."""
+    z = _load(golden_dir, "vitl_336")
+    vc = O.VitConfig(image_size=336)
+    sd = O.init_tower_weights(vc, seed=int(z["spec"][0]))
+    g = torch.Generator().manual_seed(int(z["spec"][2]))
+    images = torch.randn(2, 3, 336, 336, generator=g)
+    feats = O.tower_forward(sd, vc, images[:1], -2)
+    torch.testing.assert_close(feats, _t(z["feats"])[:1], rtol=1e-4, atol=1e-4)
+
+
+def test_llama_7b_dims_matches_hf(golden_dir):
+    """BASELINE cfg5 at Vicuna-7B layer dims (hidden 4096, 32 x 128 heads, SwiGLU 11008, vocab 32000; two layers): the oracle's prefill
+    against HuggingFace LlamaForCausalLM's stored outputs (weights regenerate from the seed)."""
+    z = _load(golden_dir, "llama_7bdims")
+    kw = {str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    seed, B, T, left = (int(v) for v in z["spec"])
+    lc = O.LlamaConfigLite(**kw)
+    sd = O.init_llama_weights(lc, seed=seed)
+    x, am, pos = O.llama_inputs(lc, seed, B, T, "left" if left else "right")
+    hidden, logits = O.llama_forward(sd, lc, x, am, pos)
+    valid = am.bool()
+    torch.testing.assert_close(hidden[valid], _t(z["hidden"])[valid], rtol=1e-5, atol=1e-5)
+    stride = 32000 // _t(z["logits_cols"]).shape[-1] + 1
+    torch.testing.assert_close(logits[:, :, ::stride][valid], _t(z["logits_cols"])[valid], rtol=1e-5, atol=1e-5)
+    for b, t in enumerate(_t(z["last"]).tolist()):
+        torch.testing.assert_close(logits[b, t], _t(z["logits_last"])[b], rtol=1e-5, atol=1e-5)
