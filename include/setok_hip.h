@@ -99,6 +99,26 @@ int setok_patchify(void* stream, int dtype, const void* images, void* patches, i
 int setok_vit_assemble(void* stream, int dtype, const void* patch_embed, const void* cls, const void* pos,
                        void* tokens, int B, int N, int C);
 
+/* ---- LayerNorm folded into the consuming Linear (bf16 throughput mode) ------------------------------------------------------
+ * HF CLIP's encoder layer (reached from clip_encoder.py:59) computes q/k/v = Linear(layer_norm1(h)) and fc1(layer_norm2(h)); the
+ * reference's Block does the same with norm1 / norm2 (module.py:88,98).  With W' = gamma * W (rounded to bf16), c = W' 1, b' = b + W beta:
+ *     LN(h) W^T + b = rstd_r * (h W'^T - mean_r * c + b' / rstd_r)
+ * so the GEMM reads the raw residual stream h and no normalised copy of it is ever written.  The fp32 parity mode keeps the separate
+ * setok_layernorm. */
+
+/* stats[r] = {mean, rstd = 1 / sqrt(var + eps)} of row r (rows x C, `dtype`), two-pass fp32 statistics in setok_layernorm's order. */
+int setok_row_stats(void* stream, int dtype, const void* x, float* stats, int rows, int C, float eps);
+
+/* Once per weight load: W (N, K) bf16, gamma / beta (K) fp32, bias (N) fp32 or NULL ->
+ * w_gamma (N, K) bf16, w_colsum (N) fp32, bias_folded (N) fp32. */
+int setok_ln_fold(void* stream, const void* W, const float* gamma, const float* beta, const float* bias, void* w_gamma,
+                  float* w_colsum, float* bias_folded, int N, int K);
+
+/* C[M,N] = act(LN(A)[M,K] . W[N,K]^T + bias) from the folded operands above and the row statistics of A (bf16 in, bf16 out;
+ * K % 64 == 0, N % 64 == 0, lda / ldc multiples of 8). */
+int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* w_colsum, const float* bias_folded,
+                    const float* row_stats, void* C, int64_t ldc, int M, int N, int K, int act);
+
 /* ---- SeTok head glue --------------------------------------------------------------------- */
 
 /* x[b,i,:] = hidden[b, i+skip, :] + pos2d[i,:] : feature_select's `[:, 1:]` (clip_encoder.py:43,
@@ -118,13 +138,17 @@ int setok_select_add_pos(void* stream, int dtype, const void* hidden, const void
  *   idx_cluster:(B, N) int64 out                       score: (B, N) fp32 out  (reference: (1,N) per image)
  *   index_down: (B, N) int64 out, first counts[b] entries valid, rest -1
  *   counts:     (B) int32 out  = L_b
- *   dist_ws:    (B, N, N) fp32 workspace (the scaled distance matrix; stays in L2/MALL at these sizes)
- *   vec_ws:     (B, 4, N) fp32 workspace (density, row max, delta, spare)
+ *   dist_ws:    fp32 workspace for the scaled distance matrix, vec_ws: fp32 workspace (density, row max, delta, spare) — sizes from
+ *               setok_cluster_workspace; both may be NULL when it reports 0 (bf16, N <= 256, C % 64 == 0: the whole call is ONE launch,
+ *               one workgroup per image, the distance matrix lives in MFMA accumulators and never reaches memory).
  * Requires N <= 1024, 1 <= k <= N, min_cluster_num <= N. */
 int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int B, int N, int C, int k,
                           float threshold, int min_cluster_num, const float* noise,
                           const float* token_mask, int64_t* idx_cluster, float* score,
                           int64_t* index_down, int32_t* counts, float* dist_ws, float* vec_ws);
+
+/* Workspace of setok_cluster_dpc_knn for a problem shape, in floats (0 = not needed). */
+int setok_cluster_workspace(int dtype, int B, int N, int C, int64_t* dist_floats, int64_t* vec_floats);
 
 /* Stable counting sort of each image's tokens by cluster id (`labels.unique()` order ==
  * ascending label, tokenizer.py:141-143) plus the segment tables the ragged stages need:

@@ -21,6 +21,9 @@ SIGNATURES = {
     "setok_last_error": [],
     "setok_device_info": [C.c_char_p, _i, C.POINTER(_i)],
     "setok_linear": [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i64, _i64, _i64],
+    "setok_row_stats": [_vp, _i, _vp, _vp, _i, _i, _f],
+    "setok_ln_fold": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
+    "setok_linear_ln": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i],
     "setok_layernorm": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f],
     "setok_activation": [_vp, _i, _vp, _vp, _i64, _i],
     "setok_attention": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f],
@@ -29,6 +32,7 @@ SIGNATURES = {
     "setok_vit_assemble": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "setok_select_add_pos": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i],
     "setok_cluster_dpc_knn": [_vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "setok_cluster_workspace": [_i, _i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)],
     "setok_cluster_sort": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "setok_gather_rows": [_vp, _i, _vp, _vp, _vp, _i, _i],
     "setok_segment_mean": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i],

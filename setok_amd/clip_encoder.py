@@ -168,7 +168,7 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
         GEMM operand, fp32 biases / LayerNorm affine."""
         vt = self.vision_tower
         # one weight per encoder layer + the embeddings: a state-dict load rewrites all of them (and fires the post-hook anyway)
-        key = (vt.dtype, str(vt.device), self._versions([l.mlp.fc1.weight for l in vt.encoder.layers]
+        key = (vt.dtype, str(vt.device), os.environ.get("SETOK_LN_FOLD", "1"), self._versions([l.mlp.fc1.weight for l in vt.encoder.layers]
                                                        + [vt.embeddings.patch_embedding.weight, vt.pre_layrnorm.weight]))
         if self._packed.get("key") == key:
             return self._packed
@@ -178,6 +178,10 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
         kpad = ops.round_up(3 * p * p, 64)
         wp = torch.zeros((C, kpad), dtype=dt, device=vt.device)
         wp[:, :3 * p * p] = vt.embeddings.patch_embedding.weight.detach().reshape(C, -1)
+        # bf16 throughput mode: layer_norm1 / layer_norm2 are folded into the q|k|v and fc1 GEMMs (ops.linear_ln); SETOK_LN_FOLD=0 keeps the
+        # separate LayerNorm pass (A/B runs).  The fp32 parity mode always keeps it.
+        fold = dt == torch.bfloat16 and vt.device.type == "cuda" and os.environ.get("SETOK_LN_FOLD", "1") != "0" and C % 64 == 0 \
+            and cfg.intermediate_size % 64 == 0
         layers = []
         for l in vt.encoder.layers:
             at = l.self_attn
@@ -189,6 +193,10 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
                 wo=at.out_proj.weight.detach().contiguous(), bo=f32(at.out_proj.bias),
                 w1=l.mlp.fc1.weight.detach().contiguous(), b1=f32(l.mlp.fc1.bias),
                 w2=l.mlp.fc2.weight.detach().contiguous(), b2=f32(l.mlp.fc2.bias)))
+            if fold:
+                d = layers[-1]
+                d["qkv_ln"] = ops.ln_fold(d["wqkv"], *d["ln1"], d["bqkv"])
+                d["fc1_ln"] = ops.ln_fold(d["w1"], *d["ln2"], d["b1"])
         self._packed = dict(key=key, kpad=kpad, wp=wp, cls=vt.embeddings.class_embedding.detach().contiguous(),
                             pos=vt.embeddings.position_embedding.weight.detach().contiguous(),
                             pre=(f32(vt.pre_layrnorm.weight), f32(vt.pre_layrnorm.bias)), layers=layers)
@@ -219,13 +227,22 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
         pe = ops.linear(patches, pk["wp"])
         h = ops.vit_assemble(pe, pk["cls"], pk["pos"], B, N)
         ops.layernorm(h, *pk["pre"], eps, out=h)
+        st = y = None
         for l in pk["layers"][: self.layers_needed()]:
-            y = ops.layernorm(h, *l["ln1"], eps)
-            qkv = ops.linear(y, l["wqkv"], l["bqkv"])
+            if "qkv_ln" in l:                          # LayerNorm folded into the consumer: statistics only, the GEMM reads the raw stream
+                st = ops.row_stats(h, eps, out=st)
+                qkv = ops.linear_ln(h, l["qkv_ln"], st)
+            else:
+                y = ops.layernorm(h, *l["ln1"], eps, out=y)
+                qkv = ops.linear(y, l["wqkv"], l["bqkv"])
             a = ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T)
             ops.linear(a, l["wo"], l["bo"], residual=h, out=h)
-            y = ops.layernorm(h, *l["ln2"], eps, out=y)
-            u = ops.linear(y, l["w1"], l["b1"], act=ops.ACT_QUICK_GELU)
+            if "fc1_ln" in l:
+                st = ops.row_stats(h, eps, out=st)
+                u = ops.linear_ln(h, l["fc1_ln"], st, act=ops.ACT_QUICK_GELU)
+            else:
+                y = ops.layernorm(h, *l["ln2"], eps, out=y)
+                u = ops.linear(y, l["w1"], l["b1"], act=ops.ACT_QUICK_GELU)
             ops.linear(u, l["w2"], l["b2"], residual=h, out=h)
         return h
 

@@ -12,6 +12,8 @@
 // mask[i,j] = rho_j > rho_i and the row-j-max quirk (:96-99), score = delta * rho (:101), first-min
 // argmin over centre rows (:111-113), centres own themselves (:117-119).
 #include "common.h"
+#include <stdlib.h>
+#include <math.h>
 
 constexpr int MAXPL = 16;          // values per lane -> N <= 1024
 
@@ -33,7 +35,7 @@ constexpr int GR_BOFF = GR_ROWS * GR_K * 2;                   // 8 KiB
 
 __device__ inline int gr_swz(int row) { return ((row >> 1) & 1) | (((row >> 4) & 1) << 1) | (((row >> 3) & 1) << 2); }
 
-__global__ __launch_bounds__(256, 2) void gram_bf16_kernel(const bf16* __restrict__ X, float* __restrict__ G, float* __restrict__ vec,
+__global__ __launch_bounds__(256, 2) void dpc_gram_bf16_kernel(const bf16* __restrict__ X, float* __restrict__ G, float* __restrict__ vec,
                                                            int B, int N, int C, int strips, int chunks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -123,8 +125,384 @@ __global__ __launch_bounds__(256, 2) void gram_bf16_kernel(const bf16* __restric
 }
 }  // namespace
 
+
+// --------------------------------------------------------------------------------------------
+// The whole of cluster_dpc_knn for ONE image in ONE workgroup, N <= 256 tokens, bf16 (the BASELINE configuration: ViT-L/14-224).
+//
+// The N x N distance matrix never exists in memory: 8 waves hold it in their MFMA accumulators (wave w owns rows [32 w, 32 w + 32) x all
+// 256 columns = 128 registers per lane) from the Gram product to the last use.  With the MFMA operands swapped (columns' fragment first) a
+// lane holds, for row (lane & 15) of each of its two 16-row tiles, the columns t * 16 + 4 * (lane >> 4) + e (t < 16, e < 4): the four lanes
+// {l, l + 16, l + 32, l + 48} own one row between them, so every per-row step (row max, the k-nearest radix select, delta, the
+// nearest-centre argmin) is 64 register operations per lane and two lane exchanges — no LDS, no memory.
+//
+//   X (N x C bf16) streams HBM -> LDS once (LDS-DMA, K-tiles of 64 channels x 256 rows = 32 KiB, three stages, two in flight); the
+//   same LDS tile feeds both MFMA operands (the Gram matrix is X X^T).
+//   norms |x_j|^2 = the Gram diagonal (out of the accumulators, through 1 KiB of LDS)
+//   d_ij = sqrt(max(|x_i|^2 + |x_j|^2 - 2 G_ij, 0)) / sqrt(C)   (torch.cdist's matmul form, tokenizer.py:82)            in place
+//   row max, density from the k nearest (radix select on the float bit pattern, counts summed over the row's four lanes)   :88-94
+//   delta / score against the other rows' density and row max (2 KiB of LDS)                                               :96-101
+//   centres: score > threshold in index order, else the min_cluster_num best (one thread per token, ballots)               :103-107
+//   assignment: argmin over the centre ROWS of column j (:111-113) = argmin over the centre COLUMNS of row j, because the matrix is
+//   symmetric bit for bit (products commute, the k order of the accumulation is the same) — so a row's lanes find it in their own
+//   registers; centres own themselves (:117-119).
+// HBM traffic = x once + the three small outputs; one launch for the whole batch, no workspace.
+// --------------------------------------------------------------------------------------------
+namespace {
+constexpr int FN = 256;                            // tokens per image the register-resident form holds
+constexpr int F_STAGE = FN * 64 * 2;               // one K-tile: 256 rows x 128 B
+constexpr int F_NST = 3;
+constexpr int F_LDS = F_NST * F_STAGE + 6 * 1024 + 64;
+
+struct FArgs {
+    const bf16* x; const float* noise; const float* tmask;
+    int64_t* idx; float* score; int64_t* index_down; int32_t* counts;
+    int N, C, k, mcn;
+    float thr, sqrtC, inv_sqrtC;
+    int scale_by_mul;                              // sqrt(C) is a power of two: multiplying by 1 / sqrt(C) is the same rounding as dividing
+    unsigned long long* tim;                       // SETOK_CLUSTER_TIMING=1: s_memtime at the phase boundaries of workgroup 0 (debug)
+};
+
+__device__ inline int f_swz(int row) { return (row >> 1) & 7; }
+
+template <bool MASKED>
+__global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_norm = reinterpret_cast<float*>(smem + F_NST * F_STAGE);      // [256]
+    float* s_rho = s_norm + 256;                                           // [256]  density; -1 for rows >= N
+    float* s_rmax = s_rho + 256;                                           // [256]  row max; +inf for rows >= N
+    float* s_score = s_rmax + 256;                                         // [256]
+    int* s_rank = reinterpret_cast<int*>(s_score + 256);                   // [256]  position of token i in the centre list
+    float* s_raw = reinterpret_cast<float*>(s_rank + 256);                 // [256]  raw row max (token_mask path)
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_raw + 256);   // [4] centre flags; [4..7] token_mask bits
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int b = blockIdx.x, N = g.N;
+    const bf16* Xb = g.x + (int64_t)b * N * g.C;
+
+    // ---- Gram ---------------------------------------------------------------------------------------------------------------------
+    unsigned src_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ f_swz(row);
+        src_off[i] = (unsigned)min(row, N - 1) * (unsigned)(g.C * 2) + kc * 16;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
+    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
+        unsigned keep;
+        const unsigned long long b64 = (unsigned long long)base;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
+    };
+    auto issue = [&](int kt) {
+        const unsigned sb = lds0 + (kt % F_NST) * F_STAGE;
+        const char* base = reinterpret_cast<const char*>(Xb) + (size_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(base, src_off[i], sb + i * 8192);
+    };
+
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m][t][e] = 0.f;
+
+    const bool stamp = g.tim && blockIdx.x == 0 && tid == 0;
+    if (stamp) g.tim[0] = __builtin_amdgcn_s_memtime();
+    const int nk = g.C / 64;
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile kt has landed (this wave's pieces); kt + 1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // everyone's pieces; everyone is done reading stage (kt - 1) % 3
+        if (kt + 2 < nk) issue(kt + 2);                                         // ... which is where K-tile kt + 2 goes
+        const char* T = smem + (kt % F_NST) * F_STAGE;
+        // Two k-steps of 32 channels; the 16 column fragments of a k-step in two batches of 8 that alternate between two register sets, so
+        // that 8 ds_read_b128 are always in flight under the 16 MFMAs of the other batch (fetched two at a time just ahead of their use —
+        // what hipcc makes of the plain loop — the wave stood at an lgkmcnt wait before every second MFMA pair).
+        const char* rowp = T + (wave * 32 + l15) * 128;
+        const char* colp = T + l15 * 128;
+        const int sw = f_swz(l15);                                              // rows t * 16 + l15: the swizzle depends on l15 only
+        auto slot = [&](int ks) { return ((ks * 4 + g4) ^ sw) << 4; };
+        bf16x8 rf0[2], rf1[2], cA[8], cB[8];
+        auto load_rows = [&](int ks, bf16x8 (&rf)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) rf[m] = *reinterpret_cast<const bf16x8*>(rowp + m * 2048 + slot(ks));
+        };
+        auto load_cols = [&](int ks, int half, bf16x8 (&cf)[8]) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cf[t] = *reinterpret_cast<const bf16x8*>(colp + (half * 8 + t) * 2048 + slot(ks));
+        };
+        auto mma = [&](int half, const bf16x8 (&cf)[8], const bf16x8 (&rf)[2]) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                acc[0][half * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[t], rf[0], acc[0][half * 8 + t], 0, 0, 0);
+                acc[1][half * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[t], rf[1], acc[1][half * 8 + t], 0, 0, 0);
+            }
+        };
+        load_rows(0, rf0); load_cols(0, 0, cA);
+        load_cols(0, 1, cB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, cA, rf0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(1, rf1); load_cols(1, 0, cA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, cB, rf0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_cols(1, 1, cB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, cA, rf1);
+        mma(1, cB, rf1);
+    }
+
+    if (stamp) g.tim[1] = __builtin_amdgcn_s_memtime();
+    // ---- norms = the diagonal: row i = 32 w + 16 m + l15 sits in tile t = 2 w + m at column offset l15 = 4 g4 + e ---------------------
+    const int row0 = wave * 32 + l15, row1 = row0 + 16;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        float dv = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t == 2 * wave + m && e == (l15 & 3)) dv = acc[m][t][e];
+        if (g4 == (l15 >> 2)) s_norm[wave * 32 + m * 16 + l15] = dv;
+    }
+    __syncthreads();
+
+    // ---- distances in place; raw row max ------------------------------------------------------------------------------------------------
+    const float INF = __builtin_inff();
+    const float n0 = s_norm[row0], n1 = s_norm[row1];
+    float mx0 = 0.f, mx1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 nj = *reinterpret_cast<const f32x4*>(s_norm + t * 16 + 4 * g4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = t * 16 + 4 * g4 + e < N;
+            float d0 = sqrtf(fmaxf((n0 + nj[e]) - 2.0f * acc[0][t][e], 0.f));
+            float d1 = sqrtf(fmaxf((n1 + nj[e]) - 2.0f * acc[1][t][e], 0.f));
+            if (g.scale_by_mul) { d0 *= g.inv_sqrtC; d1 *= g.inv_sqrtC; } else { d0 = d0 / g.sqrtC; d1 = d1 / g.sqrtC; }
+            acc[0][t][e] = ok ? d0 : INF;                                   // columns beyond N: never nearest, never a centre
+            acc[1][t][e] = ok ? d1 : INF;
+            mx0 = fmaxf(mx0, ok ? d0 : 0.f);
+            mx1 = fmaxf(mx1, ok ? d1 : 0.f);
+        }
+    }
+    mx0 = fmaxf(mx0, __shfl_xor(mx0, 16, 64)); mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
+    mx1 = fmaxf(mx1, __shfl_xor(mx1, 16, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+
+    if (stamp) g.tim[2] = __builtin_amdgcn_s_memtime();
+    // ---- token_mask (:84-86): masked columns read (global max + 1) everywhere ------------------------------------------------------------
+    constexpr bool masked = MASKED;
+    float fill = 0.f;
+    unsigned tmw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};    // token_mask bits of this lane's columns: bit (t & 7) * 4 + e of word t >> 3
+    bool tm_row0 = true, tm_row1 = true;
+    if constexpr (MASKED) {
+        if (g4 == 0) { s_raw[row0] = row0 < N ? mx0 : 0.f; s_raw[row1] = row1 < N ? mx1 : 0.f; }
+        if (tid < 256) {
+            const bool on = tid < N && g.tmask[(int64_t)b * N + tid] > 0.f;
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) s_mask[4 + wave] = bal;
+        }
+        __syncthreads();
+        float gm = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gm = fmaxf(gm, s_raw[lane + 64 * q]);
+        gm = wave_max(gm);
+        fill = gm + 1.0f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned nib = (unsigned)(s_mask[4 + (t >> 2)] >> ((t & 3) * 16 + 4 * g4)) & 0xfu;
+            tmw[t >> 3] = (t & 7) == 0 ? nib : (tmw[t >> 3] | (nib << ((t & 7) * 4)));
+        }
+        tm_row0 = (s_mask[4 + (row0 >> 6)] >> (row0 & 63)) & 1ull;
+        tm_row1 = (s_mask[4 + (row1 >> 6)] >> (row1 & 63)) & 1ull;
+        mx0 = 0.f; mx1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = t * 16 + 4 * g4 + e < N;
+                const bool on = (tmw[t >> 3] >> ((t & 7) * 4 + e)) & 1u;
+                mx0 = fmaxf(mx0, ok ? (on ? acc[0][t][e] : fill) : 0.f);
+                mx1 = fmaxf(mx1, ok ? (on ? acc[1][t][e] : fill) : 0.f);
+            }
+        mx0 = fmaxf(mx0, __shfl_xor(mx0, 16, 64)); mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
+        mx1 = fmaxf(mx1, __shfl_xor(mx1, 16, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+    }
+    // value of (row m, t, e) as the reference's masked matrix holds it
+    auto val = [&](int m, int t, int e) -> float {
+        const float d = acc[m][t][e];
+        if (!masked) return d;
+        const bool on = (tmw[t >> 3] >> ((t & 7) * 4 + e)) & 1u;
+        return (on || d == INF) ? d : fill;
+    };
+
+    // ---- density: mean of the squares of the k smallest of the row (self included), MSB-first radix select on the bit pattern ------------
+    {
+        const int k = g.k;
+        // T = the largest bit pattern with (#values < T) <= k - 1, MSB first: the k-th smallest value.  A row is finished EARLY when a candidate
+        // has exactly k values below it: the k smallest are then known as a set (`values < candidate`), which is all the sum needs — the
+        // remaining low bits only matter when values tie at the k-th place.  Typically ~18 of the 31 steps.
+        unsigned T0 = 0, T1 = 0;
+        bool done0 = false, done1 = false;
+        for (int bit = 30; bit >= 0; --bit) {
+            const unsigned c0 = T0 | (1u << bit), c1 = T1 | (1u << bit);
+            int q0 = 0, q1 = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q0 += __float_as_uint(val(0, t, e)) < c0;
+                    q1 += __float_as_uint(val(1, t, e)) < c1;
+                }
+            q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
+            q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+            if (!done0) { if (q0 <= k - 1) T0 = c0; else if (q0 == k) { T0 = c0; done0 = true; } }
+            if (!done1) { if (q1 <= k - 1) T1 = c1; else if (q1 == k) { T1 = c1; done1 = true; } }
+            if (__ballot(!(done0 && done1)) == 0ull) break;
+        }
+        float s0 = 0.f, s1 = 0.f; int q0 = 0, q1 = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = val(0, t, e), v1 = val(1, t, e);
+                const bool in0 = __float_as_uint(v0) < T0, in1 = __float_as_uint(v1) < T1;
+                s0 += in0 ? v0 * v0 : 0.f; q0 += in0;
+                s1 += in1 ? v1 * v1 : 0.f; q1 += in1;
+            }
+        s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
+        q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+        const float kth0 = __uint_as_float(T0), kth1 = __uint_as_float(T1);
+        float rho0 = expf(-((s0 + (float)(k - q0) * (kth0 * kth0)) / (float)k));
+        float rho1 = expf(-((s1 + (float)(k - q1) * (kth1 * kth1)) / (float)k));
+        if (g.noise) {
+            if (row0 < N) rho0 += g.noise[(int64_t)b * N + row0] * 1e-6f;
+            if (row1 < N) rho1 += g.noise[(int64_t)b * N + row1] * 1e-6f;
+        }
+        if (masked) { if (!tm_row0) rho0 = 0.f; if (!tm_row1) rho1 = 0.f; }        // density * token_mask (:94)
+        if (g4 == 0) {
+            s_rho[row0] = row0 < N ? rho0 : -1.0f;  s_rmax[row0] = row0 < N ? mx0 : INF;
+            s_rho[row1] = row1 < N ? rho1 : -1.0f;  s_rmax[row1] = row1 < N ? mx1 : INF;
+        }
+    }
+    __syncthreads();
+
+    if (stamp) g.tim[3] = __builtin_amdgcn_s_memtime();
+    // ---- delta_i = min_j (rho_j > rho_i ? D_ij : rowmax_j) (:96-99), score = delta * rho (:101) -----------------------------------------------
+    {
+        const float r0 = s_rho[row0], r1 = s_rho[row1];
+        float dm0 = INF, dm1 = INF;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 rj = *reinterpret_cast<const f32x4*>(s_rho + t * 16 + 4 * g4);
+            const f32x4 mj = *reinterpret_cast<const f32x4*>(s_rmax + t * 16 + 4 * g4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dm0 = fminf(dm0, rj[e] > r0 ? val(0, t, e) : mj[e]);
+                dm1 = fminf(dm1, rj[e] > r1 ? val(1, t, e) : mj[e]);
+            }
+        }
+        dm0 = fminf(dm0, __shfl_xor(dm0, 16, 64)); dm0 = fminf(dm0, __shfl_xor(dm0, 32, 64));
+        dm1 = fminf(dm1, __shfl_xor(dm1, 16, 64)); dm1 = fminf(dm1, __shfl_xor(dm1, 32, 64));
+        if (g4 == 0) {
+            const float sc0 = dm0 * r0, sc1 = dm1 * r1;
+            s_score[row0] = sc0; s_score[row1] = sc1;
+            if (row0 < N) g.score[(int64_t)b * N + row0] = sc0;
+            if (row1 < N) g.score[(int64_t)b * N + row1] = sc1;
+        }
+    }
+    __syncthreads();
+
+    if (stamp) g.tim[4] = __builtin_amdgcn_s_memtime();
+    // ---- centres (:103-107): one thread per token ----------------------------------------------------------------------------------------------------
+    if (tid < 256) {
+        const float si = tid < N ? s_score[tid] : 0.f;
+        const unsigned long long bal = __ballot(tid < N && si > g.thr);
+        if (lane == 0) s_mask[wave] = bal;
+    }
+    __syncthreads();
+    const bool none = (s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3]) == 0ull;      // uniform
+    __syncthreads();
+    if (none && tid < 256) {                                   // the min_cluster_num largest scores, ties to the lower index, in index order
+        const float si = tid < N ? s_score[tid] : 0.f;
+        int rank = 0;
+        for (int j = 0; j < N; ++j) { const float sj = s_score[j]; rank += (sj > si) || (sj == si && j < tid); }
+        const unsigned long long bal = __ballot(tid < N && rank < g.mcn);
+        if (lane == 0) s_mask[wave] = bal;
+    }
+    __syncthreads();
+    const unsigned long long cm0 = s_mask[0], cm1 = s_mask[1], cm2 = s_mask[2], cm3 = s_mask[3];
+    const int L = __builtin_popcountll(cm0) + __builtin_popcountll(cm1) + __builtin_popcountll(cm2) + __builtin_popcountll(cm3);
+    if (tid < 256) {
+        const int w = tid >> 6;
+        const unsigned long long mine = w == 0 ? cm0 : (w == 1 ? cm1 : (w == 2 ? cm2 : cm3));
+        int pos = __builtin_popcountll(mine & ((1ull << (tid & 63)) - 1ull));
+        if (w > 0) pos += __builtin_popcountll(cm0);
+        if (w > 1) pos += __builtin_popcountll(cm1);
+        if (w > 2) pos += __builtin_popcountll(cm2);
+        s_rank[tid] = pos;
+        if ((mine >> (tid & 63)) & 1ull) g.index_down[(int64_t)b * N + pos] = tid;
+        if (tid >= L && tid < N) g.index_down[(int64_t)b * N + tid] = -1;
+        if (tid == 0) g.counts[b] = L;
+    }
+    __syncthreads();
+
+    if (stamp) g.tim[5] = __builtin_amdgcn_s_memtime();
+    // ---- assignment (:111-119): first argmin over the centres, read along the token's OWN row (the matrix is symmetric) -------------------------------------
+    {
+        float b0 = INF, b1 = INF; int j0 = 0x7fffffff, j1 = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned long long wsel = (t >> 2) == 0 ? cm0 : ((t >> 2) == 1 ? cm1 : ((t >> 2) == 2 ? cm2 : cm3));
+            const unsigned nib = (unsigned)(wsel >> ((t & 3) * 16 + 4 * g4)) & 0xfu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool c = (nib >> e) & 1u;
+                const int j = t * 16 + 4 * g4 + e;
+                const float v0 = acc[0][t][e], v1 = acc[1][t][e];             // D[centre][token] is the RAW distance when the token is unmasked
+                if (c && v0 < b0) { b0 = v0; j0 = j; }
+                if (c && v1 < b1) { b1 = v1; j1 = j; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ob0 = __shfl_xor(b0, o, 64), ob1 = __shfl_xor(b1, o, 64);
+            const int oj0 = __shfl_xor(j0, o, 64), oj1 = __shfl_xor(j1, o, 64);
+            if (ob0 < b0 || (ob0 == b0 && oj0 < j0)) { b0 = ob0; j0 = oj0; }
+            if (ob1 < b1 || (ob1 == b1 && oj1 < j1)) { b1 = ob1; j1 = oj1; }
+        }
+        if (g4 == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int row = m ? row1 : row0;
+                if (row >= N) continue;
+                const int jb = m ? j1 : j0;
+                const bool tm_on = m ? tm_row1 : tm_row0;
+                int lab = ((masked && !tm_on) || jb >= FN) ? 0 : s_rank[jb];                 // a masked token's column reads `fill` in every centre row: first index
+                const unsigned long long wsel = (row >> 6) == 0 ? cm0 : ((row >> 6) == 1 ? cm1 : ((row >> 6) == 2 ? cm2 : cm3));
+                if ((wsel >> (row & 63)) & 1ull) lab = s_rank[row];             // a centre owns itself
+                g.idx[(int64_t)b * N + row] = lab;
+            }
+        }
+    }
+    if (stamp) g.tim[6] = __builtin_amdgcn_s_memtime();
+}
+}  // namespace
+
 // |x_i|^2 = G_ii (the same fma chain as every other Gram entry) -> vec[b][3][i]
-__global__ void diag_kernel(const float* __restrict__ G, float* __restrict__ vec, int B, int N) {
+__global__ void dpc_diag_kernel(const float* __restrict__ G, float* __restrict__ vec, int B, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * N) return;
     const int b = i / N, r = i % N;
@@ -160,7 +538,7 @@ __device__ inline float knn_sqsum(const float (&v)[MAXPL], int lane, int N, int 
 // One wave per row i of image b.  G (in/out): Gram row -> scaled distance row.
 // vec layout per image: [0] density, [1] row max, [2] delta, [3] norms (later: centre list as int32)
 template <bool WITH_DENSITY, int PL>
-__global__ __launch_bounds__(256) void dist_rows_kernel(float* __restrict__ G, float* __restrict__ vec, const float* __restrict__ noise,
+__global__ __launch_bounds__(256) void dpc_dist_rows_kernel(float* __restrict__ G, float* __restrict__ vec, const float* __restrict__ noise,
                                                         int B, int N, int k, float sqrtC) {
     const int lane = threadIdx.x & 63;
     const int gr = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -193,7 +571,7 @@ __global__ __launch_bounds__(256) void dist_rows_kernel(float* __restrict__ G, f
 }
 
 // token_mask path (:84-86, :93-94): gmax[b] = max of the raw distance matrix
-__global__ void gmax_kernel(const float* __restrict__ vec, float* __restrict__ gmax, int N) {
+__global__ void dpc_gmax_kernel(const float* __restrict__ vec, float* __restrict__ gmax, int N) {
     const int b = blockIdx.x;
     float m = 0.f;
     for (int j = threadIdx.x; j < N; j += 64) m = fmaxf(m, vec[((int64_t)b * 4 + 1) * N + j]);
@@ -202,7 +580,7 @@ __global__ void gmax_kernel(const float* __restrict__ vec, float* __restrict__ g
 }
 
 template <int PL>
-__global__ __launch_bounds__(256) void masked_density_kernel(float* __restrict__ D, float* __restrict__ vec, const float* __restrict__ noise,
+__global__ __launch_bounds__(256) void dpc_masked_density_kernel(float* __restrict__ D, float* __restrict__ vec, const float* __restrict__ noise,
                                                              const float* __restrict__ tmask, const float* __restrict__ gmax,
                                                              int B, int N, int k) {
     const int lane = threadIdx.x & 63;
@@ -235,7 +613,7 @@ __global__ __launch_bounds__(256) void masked_density_kernel(float* __restrict__
 }
 
 // delta_i = min_j (rho_j > rho_i ? D_ij : rowmax_j);  score_i = delta_i * rho_i
-__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ D, float* __restrict__ vec, float* __restrict__ score,
+__global__ __launch_bounds__(256) void dpc_score_kernel(const float* __restrict__ D, float* __restrict__ vec, float* __restrict__ score,
                                                     int B, int N) {
     const int lane = threadIdx.x & 63;
     const int gr = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -256,7 +634,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ D,
 
 // One workgroup per image: centres = {i : score_i > thr} in index order; if none, the
 // min_cluster_num largest scores (ties: lower index first) in index order.
-__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ score, float thr, int mcn, int N,
+__global__ __launch_bounds__(256) void dpc_select_kernel(const float* __restrict__ score, float thr, int mcn, int N,
                                                      int64_t* __restrict__ index_down, int32_t* __restrict__ counts,
                                                      float* __restrict__ vec) {
     __shared__ float s[1024];
@@ -302,7 +680,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ s
 }
 
 // label_j = first argmin_c D[centre_c][j]; centres relabelled to their own position.
-__global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ D, const float* __restrict__ vec,
+__global__ __launch_bounds__(256) void dpc_assign_kernel(const float* __restrict__ D, const float* __restrict__ vec,
                                                      const int32_t* __restrict__ counts, int64_t* __restrict__ idx, int N) {
     __shared__ int cs[1024];
     const int b = blockIdx.y;
@@ -327,50 +705,87 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ D
     idx[(int64_t)b * N + j] = lab;
 }
 
+static bool fused_disabled() {                      // SETOK_CLUSTER_FUSED=0: the multi-kernel path for every shape (A/B runs, tests of that path);
+    const char* e = getenv("SETOK_CLUSTER_FUSED");  // read per call so that one process can exercise both
+    return e && e[0] == '0';
+}
+
+extern "C" int setok_cluster_workspace(int dtype, int B, int N, int C, int64_t* dist_floats, int64_t* vec_floats) {
+    SETOK_CHECK_ARG(dist_floats && vec_floats && B >= 0 && N > 0 && C > 0, "setok_cluster_workspace: bad argument");
+    const bool fused = dtype == SETOK_BF16 && C % 64 == 0 && N <= FN && !fused_disabled();
+    *dist_floats = fused ? 0 : (int64_t)B * N * N;
+    *vec_floats = fused ? 0 : (int64_t)B * 4 * N;
+    return SETOK_OK;
+}
+
 extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int B, int N, int C, int k,
                                      float threshold, int min_cluster_num, const float* noise,
                                      const float* token_mask, int64_t* idx_cluster, float* score,
                                      int64_t* index_down, int32_t* counts, float* dist_ws, float* vec_ws) {
-    SETOK_CHECK_ARG(x && idx_cluster && score && index_down && counts && dist_ws && vec_ws, "setok_cluster_dpc_knn: null operand");
+    SETOK_CHECK_ARG(x && idx_cluster && score && index_down && counts, "setok_cluster_dpc_knn: null operand");
     SETOK_CHECK_ARG(B > 0 && N > 0 && N <= 64 * MAXPL && C > 0, "setok_cluster_dpc_knn: need 0 < N <= %d (got N=%d)", 64 * MAXPL, N);
     SETOK_CHECK_ARG(k >= 1 && k <= N, "setok_cluster_dpc_knn: k=%d out of range (torch.topk would raise), N=%d", k, N);
     SETOK_CHECK_ARG(min_cluster_num >= 1 && min_cluster_num <= N, "setok_cluster_dpc_knn: min_cluster_num=%d out of range, N=%d", min_cluster_num, N);
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * N;
     const float sqrtC = (float)sqrt((double)C);
+    if (dtype == SETOK_BF16 && C % 64 == 0 && N <= FN && !fused_disabled()) {
+        // the whole call in one launch, one workgroup per image, no workspace (the BASELINE configuration)
+        static SetokDeviceOnce once_f;
+        if (!once_f.run([] { return hipFuncSetAttribute((const void*)dpc_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) == hipSuccess &&
+                                    hipFuncSetAttribute((const void*)dpc_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) == hipSuccess; }))
+            return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot raise the dynamic LDS limit");
+        int ex = 0;
+        const float mant = frexpf(sqrtC, &ex);
+        static const bool timing = [] { const char* e = getenv("SETOK_CLUSTER_TIMING"); return e && e[0] == '1'; }();
+        static unsigned long long* tim = nullptr;
+        if (timing && !tim && hipMalloc(&tim, 8 * 8) != hipSuccess) tim = nullptr;
+        FArgs a{(const bf16*)x, noise, token_mask, idx_cluster, score, index_down, counts, N, C, k, min_cluster_num, threshold, sqrtC, 1.0f / sqrtC,
+                mant == 0.5f ? 1 : 0, timing ? tim : nullptr};
+        if (token_mask) dpc_fused_kernel<true><<<B, 512, F_LDS, s>>>(a); else dpc_fused_kernel<false><<<B, 512, F_LDS, s>>>(a);
+        SETOK_CHECK_LAUNCH("setok_cluster_dpc_knn(fused)");
+        if (timing && tim) {
+            unsigned long long h[8];
+            if (hipMemcpy(h, tim, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[cluster timing] B=%d N=%d C=%d  cycles of workgroup 0: gram %llu, distances %llu, density %llu, delta %llu, centres %llu, assignment %llu, total %llu\n",
+                        B, N, C, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        }
+        return SETOK_OK;
+    }
+    SETOK_CHECK_ARG(dist_ws && vec_ws, "setok_cluster_dpc_knn: this shape needs the distance workspace (setok_cluster_workspace)");
     if (dtype == SETOK_BF16 && C % GR_K == 0) {
         // Gram matrices + diagonals in one launch (bf16 throughput mode)
         static SetokDeviceOnce once;
-        if (!once.run([] { return hipFuncSetAttribute((const void*)gram_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GR_STAGE) == hipSuccess; }))
+        if (!once.run([] { return hipFuncSetAttribute((const void*)dpc_gram_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GR_STAGE) == hipSuccess; }))
             return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot raise the dynamic LDS limit");
         const int strips = cdiv(N, GR_ROWS), chunks = cdiv(N, GR_COLS);
-        gram_bf16_kernel<<<cdiv(B, 8) * 8 * strips * chunks, 256, 2 * GR_STAGE, s>>>((const bf16*)x, dist_ws, vec_ws, B, N, C, strips, chunks);
+        dpc_gram_bf16_kernel<<<cdiv(B, 8) * 8 * strips * chunks, 256, 2 * GR_STAGE, s>>>((const bf16*)x, dist_ws, vec_ws, B, N, C, strips, chunks);
     } else {
         // fp32 parity mode: batched exact-f32 MFMA GEMM with A = W = X_b, then |x_i|^2 = G_ii
         int rc = setok_linear(stream, dtype, SETOK_F32, x, C, x, nullptr, nullptr, dist_ws, N, N, N, C, SETOK_ACT_NONE, B,
                               (int64_t)N * C, (int64_t)N * C, (int64_t)N * N);
         if (rc != SETOK_OK) return rc;
-        diag_kernel<<<cdiv(rows, 256), 256, 0, s>>>(dist_ws, vec_ws, B, N);
+        dpc_diag_kernel<<<cdiv(rows, 256), 256, 0, s>>>(dist_ws, vec_ws, B, N);
     }
     const int pl = N <= 256 ? 4 : (N <= 576 ? 9 : MAXPL);             // register slots per lane holding one distance row
     const dim3 rg(cdiv(rows, 4));
     if (!token_mask) {
-        if (pl == 4) dist_rows_kernel<true, 4><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
-        else if (pl == 9) dist_rows_kernel<true, 9><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
-        else dist_rows_kernel<true, MAXPL><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
+        if (pl == 4) dpc_dist_rows_kernel<true, 4><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
+        else if (pl == 9) dpc_dist_rows_kernel<true, 9><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
+        else dpc_dist_rows_kernel<true, MAXPL><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
     } else {
-        if (pl == 4) dist_rows_kernel<false, 4><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
-        else if (pl == 9) dist_rows_kernel<false, 9><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
-        else dist_rows_kernel<false, MAXPL><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
-        float* gmax = reinterpret_cast<float*>(counts);                 // B floats of scratch until select_kernel overwrites it
-        gmax_kernel<<<B, 64, 0, s>>>(vec_ws, gmax, N);
-        if (pl == 4) masked_density_kernel<4><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, token_mask, gmax, B, N, k);
-        else if (pl == 9) masked_density_kernel<9><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, token_mask, gmax, B, N, k);
-        else masked_density_kernel<MAXPL><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, token_mask, gmax, B, N, k);
+        if (pl == 4) dpc_dist_rows_kernel<false, 4><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
+        else if (pl == 9) dpc_dist_rows_kernel<false, 9><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
+        else dpc_dist_rows_kernel<false, MAXPL><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, B, N, k, sqrtC);
+        float* gmax = reinterpret_cast<float*>(counts);                 // B floats of scratch until dpc_select_kernel overwrites it
+        dpc_gmax_kernel<<<B, 64, 0, s>>>(vec_ws, gmax, N);
+        if (pl == 4) dpc_masked_density_kernel<4><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, token_mask, gmax, B, N, k);
+        else if (pl == 9) dpc_masked_density_kernel<9><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, token_mask, gmax, B, N, k);
+        else dpc_masked_density_kernel<MAXPL><<<rg, 256, 0, s>>>(dist_ws, vec_ws, noise, token_mask, gmax, B, N, k);
     }
-    score_kernel<<<cdiv(rows, 4), 256, 0, s>>>(dist_ws, vec_ws, score, B, N);
-    select_kernel<<<B, 256, 0, s>>>(score, threshold, min_cluster_num, N, index_down, counts, vec_ws);
-    assign_kernel<<<dim3(cdiv(N, 256), B), 256, 0, s>>>(dist_ws, vec_ws, counts, idx_cluster, N);
+    dpc_score_kernel<<<cdiv(rows, 4), 256, 0, s>>>(dist_ws, vec_ws, score, B, N);
+    dpc_select_kernel<<<B, 256, 0, s>>>(score, threshold, min_cluster_num, N, index_down, counts, vec_ws);
+    dpc_assign_kernel<<<dim3(cdiv(N, 256), B), 256, 0, s>>>(dist_ws, vec_ws, counts, idx_cluster, N);
     SETOK_CHECK_LAUNCH("setok_cluster_dpc_knn");
     return SETOK_OK;
 }

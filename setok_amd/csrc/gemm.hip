@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                            bf16* C, int64_t ldc, int M, int N, int K, int act);    // gemm_persist.hip
+                            bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum);    // gemm_persist.hip
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                          bf16* C, int64_t ldc, int M, int N, int K, int act);      // gemm_persist.hip
+                          bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum);      // gemm_persist.hip
 int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
                                    int64_t sA, int64_t sW, int64_t sC);               // gemm_persist.hip
 
@@ -251,7 +251,7 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
         // big problems (>= 48 tiles of 256x256; measured crossover against the 64x64 kernel: ~50 tiles): persistent direct-to-LDS kernel (gemm_persist.hip)
         static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();   // test hook
         if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= persist_min && !g_force_small_tiles)
-            return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
+            return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr);
         // fp32-out batched problems without bias / activation / residual and with enough tiles (weight-gradient partial products)
         if (out_dtype == SETOK_F32 && !bias && !residual && act == SETOK_ACT_NONE && N % 64 == 0 && K >= 192 && ldc % 4 == 0 &&
             strideA % 8 == 0 && strideW % 8 == 0 && strideC % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) * batch >= 96 && !g_force_small_tiles)
@@ -261,7 +261,7 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
         {
             static const int small_max = [] { const char* e = getenv("SETOK_GEMM_SMALL64_MAXTILES"); return e ? atoi(e) : 0x7fffffff; }();
             if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && ldc % 8 == 0 && cdiv(M, BM) * cdiv(N, BN) <= small_max && !g_force_small_tiles)
-                return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act);
+                return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr);
         }
         dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
         if (out_dtype == SETOK_BF16) gemm_bf16_kernel<bf16, true><<<grid, 256, 0, s>>>(g);
@@ -278,4 +278,21 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
     }
     SETOK_CHECK_LAUNCH("setok_linear");
     return SETOK_OK;
+}
+
+// LayerNorm folded into the consuming Linear (bf16 throughput mode; gemm_persist.hip explains the algebra).  Same kernel choice as
+// setok_linear makes for a bf16 -> bf16 problem, so a row's result does not depend on the batch it is computed in.
+extern "C" int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* w_colsum, const float* bias_folded,
+                               const float* row_stats, void* C, int64_t ldc, int M, int N, int K, int act) {
+    SETOK_CHECK_ARG(A && w_gamma && w_colsum && bias_folded && row_stats && C, "setok_linear_ln: null operand");
+    SETOK_CHECK_ARG(M >= 0 && N > 0 && K > 0, "setok_linear_ln: bad shape M=%d N=%d K=%d", M, N, K);
+    SETOK_CHECK_ARG(act >= SETOK_ACT_NONE && act <= SETOK_ACT_GELU_ERF, "setok_linear_ln: bad act %d", act);
+    SETOK_CHECK_ARG(K % BK == 0 && N % 64 == 0 && lda >= K && ldc >= N && lda % 8 == 0 && ldc % 8 == 0,
+                    "setok_linear_ln: needs K %% 64 == 0, N %% 64 == 0, 16-byte aligned rows (M=%d N=%d K=%d)", M, N, K);
+    if (M == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();
+    if (K >= 192 && cdiv(M, 256) * cdiv(N, 256) >= persist_min)
+        return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, bias_folded, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, w_colsum);
+    return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, bias_folded, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, w_colsum);
 }

@@ -42,6 +42,8 @@ struct PArgs {
     float* Cf;                   // F32B variant: fp32 output, `nbatch` independent problems (split-K partial products of a weight gradient)
     int64_t sA, sW, sC;          //   element strides between the batch members
     int nbatch;
+    const float* ln_stats;       // LNK variant: per row of A {mean, rstd} (setok_row_stats): the LayerNorm folded into this GEMM
+    const float* ln_colsum;      //   c[n] = sum_k W'[n][k], W' = bf16(gamma * W);  `bias` then holds b'[n] = b[n] + sum_k W[n][k] beta[k]
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -57,6 +59,44 @@ __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retire
 // rows of either parity fall on eight different slots for every c -> conflict-free.
 __device__ inline int swz(int row) { return (row >> 1) & 7; }
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm folded into the consuming GEMM (bf16 throughput mode).  With W' = gamma * W:
+//     LN(x) W^T + b  =  rstd_r * ( x W'^T  -  mean_r * c  +  b' / rstd_r ),      c = W' 1,   b' = b + W beta
+// so the GEMM streams the RAW residual stream x through the unchanged LDS-DMA operand path (no normalised copy of x is ever written or
+// read: the separate LayerNorm pass was 5 % of the encode step), the accumulators START at the rank-2 correction
+// (-mean_r) c_n + (1 / rstd_r) b'_n — formed by the matrix pipe itself from two-way bf16 splits (8 k-slots of one 16x16x32 MFMA) —
+// and the epilogue multiplies by rstd_r.  Both GEMM kernels build the fragments with the functions below, so a row's result does not
+// depend on which kernel produced it.
+// --------------------------------------------------------------------------------------------
+__device__ inline void split2(float x, bf16& hi, bf16& lo) {           // x = hi + lo + O(2^-16 |x|), both by truncation
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    hi = __builtin_bit_cast(bf16, (unsigned short)(u >> 16));
+    const float r = x - __builtin_bit_cast(float, u & 0xffff0000u);
+    lo = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r) >> 16));
+}
+__device__ inline bf16x8 ln_col_frag(float c, float b, int g4) {        // the W-side operand: output column (lane & 15); k-slots 0-7 live in lanes 0-15
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16)0.0f;
+    if (g4 == 0) {
+        bf16 ch, cl, bh, bl;
+        split2(c, ch, cl); split2(b, bh, bl);
+        f[0] = ch; f[1] = ch; f[2] = cl; f[3] = cl; f[4] = bh; f[5] = bh; f[6] = bl; f[7] = bl;
+    }
+    return f;
+}
+__device__ inline bf16x8 ln_row_frag(float mean, float rstd, int g4) {  // the activation-side operand: output row (lane & 15)
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16)0.0f;
+    if (g4 == 0) {
+        bf16 mh, ml, sh, sl;
+        split2(-mean, mh, ml); split2(1.0f / rstd, sh, sl);
+        f[0] = mh; f[1] = ml; f[2] = mh; f[3] = ml; f[4] = sh; f[5] = sl; f[6] = sh; f[7] = sl;
+    }
+    return f;
+}
 
 template <int N_>
 __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
@@ -79,8 +119,10 @@ __device__ float kZeroBias[64];                    // stands in for a null bias 
 // are weight-gradient sized, store efficiency is irrelevant) for a BATCH of problems sharing M, N, K — the split-K partial products of
 // dW = dY^T X (training.py), which by themselves have too few output tiles to fill the chip.
 // RESK: the launch has a residual (its own instantiation: the residual rows' registers and code do not burden the kernels without one).
-template <int ACT, bool F32B, bool RESK = false>
+// LNK: the LayerNorm of the A rows is folded in (see above): accumulators start at the rank-2 correction, the epilogue scales by rstd.
+template <int ACT, bool F32B, bool RESK = false, bool LNK = false>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
+    static_assert(!(LNK && (F32B || RESK)), "the folded LayerNorm feeds qkv / fc1: bf16 out, no residual");
     constexpr int WNC = 4, WR = 128, MI = 4, TNB = 256;   // MI: 32-row epilogue passes per wave
     constexpr int MT = 8, NT = 4;                           // 16 x 16 MFMA tiles per wave: 8 along M (128 rows) x 4 along N (64 columns)
     constexpr int NL = 8;                          // LDS-DMA ops per lane per K-tile
@@ -154,18 +196,30 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     // holds the bias split into three bf16 parts (hi + mid + lo = the fp32 value exactly) against a fragment of ones: acc = 0 + hi + mid + lo
     // is exact, so the arithmetic (bias first, then the products in ascending k) is unchanged bit for bit.
     float nb[NT];
-    auto load_bias = [&](int n0_) {
+    float ncs[LNK ? NT : 1];                        // LNK: column sums of W' for the same columns,
+    float nmean[LNK ? MT : 1], nrstd[LNK ? MT : 1]; //      {mean, rstd} of the rows (t * 16 + l15 of the wave's 128) of the NEXT tile
+    auto load_bias = [&](int n0_, int m0_) {
         if constexpr (!F32B) {
             const float* bp = g.bias ? g.bias + min(n0_ + wn * 64, g.N - 64) : g.zero_bias;
 #pragma unroll
             for (int j = 0; j < NT; ++j) nb[j] = bp[j * 16 + l15];
+        }
+        if constexpr (LNK) {
+            const float* cp = g.ln_colsum + min(n0_ + wn * 64, g.N - 64);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ncs[j] = cp[j * 16 + l15];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float2 st = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (int64_t)min(m0_ + wm * WR + t * 16 + l15, g.M - 1));
+                nmean[t] = st.x; nrstd[t] = st.y;
+            }
         }
     };
 
     int m0, n0, round = 0;
     if (!tile_of(0, m0, n0, bz)) return;
     set_src(m0, n0, bz);
-    load_bias(n0);
+    load_bias(n0, m0);
     issue_ktile(0, 0);
     issue_ktile(1, TK);
     int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
@@ -236,7 +290,20 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
         }
         s_barrier_lgkm();
-        {   // ---- accumulators start at the bias (fp32, added before the single bf16 rounding) -------------------------------------------
+        if constexpr (LNK) {   // ---- accumulators start at (-mean_r) c_n + (1 / rstd_r) b'_n ---------------------------------------------------
+            bf16x8 cfr[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cfr[j] = ln_col_frag(ncs[j], nb[j], g4);
+            f32x4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const bf16x8 rfr = ln_row_frag(nmean[t], nrstd[t], g4);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
+            }
+        } else {   // ---- accumulators start at the bias (fp32, added before the single bf16 rounding) -------------------------------------------
             bf16x8 ones;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
@@ -310,14 +377,19 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             }
         };
         s_barrier_lgkm();
-        if (has_next) { set_src(nm0, nn0, nbz); if (!RESK) load_bias(nn0); }       // addresses first, loads after: no reload lands behind a DMA
+        if (has_next) { set_src(nm0, nn0, nbz); if (!RESK && !LNK) load_bias(nn0, nm0); }       // addresses first, loads after: no reload lands behind a DMA
         if (use_res) { if (interior) load_residual(yes{}, 0); else load_residual(no{}, 0); }
+        float er[LNK ? MT : 1];                     // LNK: rstd of THIS tile's rows for the epilogue, fetched under the last K-tile
+        if constexpr (LNK) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) er[t] = g.ln_stats[2 * (int64_t)min(m0 + wm * WR + t * 16 + l15, g.M - 1) + 1];
+        }
         multiply(yes{}, has_next, 0);                                              // last K-tile; the next tile's first one goes out
         const unsigned long long ts1 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
         s_barrier_lgkm();                                                          // every wave is done with the stage just multiplied: it
                                                                                    // receives the next tile's SECOND K-tile inside pass 0
         // One 32-row MFMA tile per pass through this wave's private 4 KiB of staging.
-        if (RESK && has_next) load_bias(nn0);          // (with a residual the registers are tighter during the last K-tile: fetched here, still ahead of the stores)
+        if ((RESK || LNK) && has_next) load_bias(nn0, nm0);   // (with a residual / the row statistics the registers are tighter during the last K-tile: fetched here, still ahead of the stores)
         auto epilogue = [&](auto res_tag, auto int_tag) {
             constexpr bool RES = decltype(res_tag)::value, INT = decltype(int_tag)::value;
 #pragma unroll
@@ -330,6 +402,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[2 * h + tt][j][e];
+                            if constexpr (LNK) x *= er[2 * h + tt];
                             if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
                             else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                             v[e] = (bf16)x;
@@ -405,9 +478,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 constexpr int TT = 64;                           // tail tile edge
 constexpr int TSTAGE = 2 * TT * TK * 2;          // A 8 KiB + W 8 KiB
 constexpr int TNS = 8;                           // stages
-constexpr int TAIL_LDS = TNS * TSTAGE + 256;     // + bias row
+constexpr int TAIL_LDS = TNS * TSTAGE + 1024;    // + bias row (+ LNK: column sums, row means, row rstds)
 
-template <int ACT>
+template <int ACT, bool LNK = false>
 __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -418,6 +491,13 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TT;
     float* sbias = reinterpret_cast<float*>(smem + TNS * TSTAGE);
     if (tid < 64) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
+    if constexpr (LNK) {                                    // sbias[64..127] column sums, [128..191] row means, [192..255] row rstds
+        if (tid < 64) {
+            sbias[64 + tid] = g.ln_colsum[min(n0 + tid, g.N - 1)];
+            const float2 st = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (int64_t)min(m0 + tid, g.M - 1));
+            sbias[128 + tid] = st.x; sbias[192 + tid] = st.y;
+        }
+    }
 
     const bf16* a_src[2]; const bf16* b_src[2];
 #pragma unroll
@@ -457,13 +537,28 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
         s_barrier_lgkm();                                   // everyone's pieces; everyone is done with the stage of K-tile kt - 1 ...
         if (kt + TNS - 1 < nk) issue(kt + TNS - 1);         // ... which is the stage K-tile kt + 7 goes to
         if (kt == 0) {
+            if constexpr (LNK) {                                // the same fragments, the same instruction as the persistent kernel: identical bits
+                f32x4 z;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int e = 0; e < 4; ++e) z[e] = 0.f;
+                bf16x8 cfr[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float b = sbias[wn * 32 + j * 16 + 4 * g4 + e];
-                    acc[0][j][e] = b; acc[1][j][e] = b;
+                for (int j = 0; j < 2; ++j) cfr[j] = ln_col_frag(sbias[64 + wn * 32 + j * 16 + l15], sbias[wn * 32 + j * 16 + l15], g4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 rfr = ln_row_frag(sbias[128 + wm * 32 + t * 16 + l15], sbias[192 + wm * 32 + t * 16 + l15], g4);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = sbias[wn * 32 + j * 16 + 4 * g4 + e];
+                        acc[0][j][e] = b; acc[1][j][e] = b;
+                    }
+            }
         }
         const char* Ab = smem + (kt % TNS) * TSTAGE;
         const char* Bb = Ab + TT * TK * 2;
@@ -493,6 +588,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[t][j][e];
+                if constexpr (LNK) x *= sbias[192 + wm * 32 + t * 16 + l15];
                 if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
                 else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                 v[e] = (bf16)x;
@@ -521,12 +617,18 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 int launch_tail(hipStream_t s, const PArgs& g, int act) {
     static SetokDeviceOnce once;
     if (!once.run([] {
-            bool ok = hipFuncSetAttribute((const void*)gemm_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
-            ok = ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
-            return ok && hipFuncSetAttribute((const void*)gemm_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess; }))
+            bool ok = true;
+            const void* fns[] = {(const void*)gemm_tail_kernel<0>, (const void*)gemm_tail_kernel<1>, (const void*)gemm_tail_kernel<2>,
+                                 (const void*)gemm_tail_kernel<0, true>, (const void*)gemm_tail_kernel<1, true>, (const void*)gemm_tail_kernel<2, true>};
+            for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+            return ok; }))
         return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
     const int grid = g.tilesM * g.tilesN;
-    if (act == SETOK_ACT_NONE) gemm_tail_kernel<0><<<grid, 256, TAIL_LDS, s>>>(g);
+    if (g.ln_stats) {
+        if (act == SETOK_ACT_NONE) gemm_tail_kernel<0, true><<<grid, 256, TAIL_LDS, s>>>(g);
+        else if (act == SETOK_ACT_QUICK_GELU) gemm_tail_kernel<1, true><<<grid, 256, TAIL_LDS, s>>>(g);
+        else gemm_tail_kernel<2, true><<<grid, 256, TAIL_LDS, s>>>(g);
+    } else if (act == SETOK_ACT_NONE) gemm_tail_kernel<0><<<grid, 256, TAIL_LDS, s>>>(g);
     else if (act == SETOK_ACT_QUICK_GELU) gemm_tail_kernel<1><<<grid, 256, TAIL_LDS, s>>>(g);
     else gemm_tail_kernel<2><<<grid, 256, TAIL_LDS, s>>>(g);
     SETOK_CHECK_LAUNCH("setok_linear(tail)");
@@ -539,13 +641,22 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
             bool ok = true;
             const void* fns[] = {(const void*)gemm_persist_kernel<0, false, false>, (const void*)gemm_persist_kernel<1, false, false>,
                                  (const void*)gemm_persist_kernel<2, false, false>, (const void*)gemm_persist_kernel<0, false, true>,
-                                 (const void*)gemm_persist_kernel<1, false, true>, (const void*)gemm_persist_kernel<2, false, true>};
+                                 (const void*)gemm_persist_kernel<1, false, true>, (const void*)gemm_persist_kernel<2, false, true>,
+                                 (const void*)gemm_persist_kernel<0, false, false, true>, (const void*)gemm_persist_kernel<1, false, false, true>,
+                                 (const void*)gemm_persist_kernel<2, false, false, true>};
             for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
             return ok; }))
         return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
+    if (g.ln_stats) {
+        if (act == SETOK_ACT_NONE) gemm_persist_kernel<0, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);
+        else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);
+        else gemm_persist_kernel<2, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);
+        SETOK_CHECK_LAUNCH("setok_linear_ln(persistent)");
+        return SETOK_OK;
+    }
     if (act == SETOK_ACT_NONE) { if (res) gemm_persist_kernel<0, false, true><<<grid, 512, MAIN_LDS, s>>>(g); else gemm_persist_kernel<0, false, false><<<grid, 512, MAIN_LDS, s>>>(g); }
     else if (act == SETOK_ACT_QUICK_GELU) { if (res) gemm_persist_kernel<1, false, true><<<grid, 512, MAIN_LDS, s>>>(g); else gemm_persist_kernel<1, false, false><<<grid, 512, MAIN_LDS, s>>>(g); }
     else { if (res) gemm_persist_kernel<2, false, true><<<grid, 512, MAIN_LDS, s>>>(g); else gemm_persist_kernel<2, false, false><<<grid, 512, MAIN_LDS, s>>>(g); }
@@ -574,7 +685,7 @@ const float* zero_bias() {                          // the current device's copy
 
 // Called by setok_linear (gemm.hip) for bf16 -> bf16 problems with >= 48 tiles of 256x256.
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                            bf16* C, int64_t ldc, int M, int N, int K, int act) {
+                            bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum) {
     const int ncu = cu_count();
     const int tilesM = cdiv(M, TM), tilesN = cdiv(N, 256);
     // Peel off p <= 2 trailing M-tiles when that leaves the main launch an exact number of rounds: the
@@ -599,7 +710,8 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
-    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1};
+    PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1,
+            ln_stats, ln_colsum};
     if (!bias) {
         const float* zb = zero_bias();
         if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
@@ -619,15 +731,16 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (rc != SETOK_OK || p == 0) return rc;
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
-            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1};
+            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1,
+            ln_stats ? ln_stats + 2 * (int64_t)m_off : nullptr, ln_colsum};
     return launch_tail(s, t, act);
 }
 
 // Called by setok_linear for SMALL bf16 -> bf16 problems (a handful of images: too few 128 x 128 tiles to fill 256 CUs): the deep-pipelined
 // 64 x 64 kernel over the whole problem.
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                          bf16* C, int64_t ldc, int M, int N, int K, int act) {
-    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, TT), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1};
+                          bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum) {
+    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, TT), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum};
     return launch_tail(s, t, act);
 }
 
@@ -641,7 +754,7 @@ int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, co
     const float* zb = zero_bias();
     if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
     const int tilesM = cdiv(M, TM), tilesN = cdiv(N, 256);
-    PArgs g{A, W, nullptr, nullptr, nullptr, lda, ldc, M, N, K, tilesM, tilesN, 0, nullptr, zb, C, sA, sW, sC, batch};
+    PArgs g{A, W, nullptr, nullptr, nullptr, lda, ldc, M, N, K, tilesM, tilesN, 0, nullptr, zb, C, sA, sW, sC, batch, nullptr, nullptr};
     const int tiles = tilesM * tilesN * batch, ncu = cu_count();
     gemm_persist_kernel<0, true><<<tiles < ncu ? tiles : ncu, 512, MAIN_LDS, s>>>(g);
     SETOK_CHECK_LAUNCH("setok_linear(persistent, fp32 batched)");

@@ -108,6 +108,104 @@ extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const flo
 }
 
 // --------------------------------------------------------------------------------------------
+// The two small pieces of a LayerNorm that is folded into its consuming GEMM (setok_linear_ln):
+//   row statistics {mean, rstd} — the first two passes of the kernels above, same summation order, no normalised copy written;
+//   the weight fold, once per weight load:  W' = bf16(gamma * W),  c = W' 1 (fp32, ascending k),  b' = b + W beta.
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int rows, int C, float eps) {
+    constexpr int V = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int row = wave0; row < rows; row += nwaves) {
+        const T* xr = x + (int64_t)row * C;
+        float buf[V];
+        float s = 0.f;
+        for (int c = lane * V; c < C; c += 64 * V) {
+            ld_vec<T>(xr + c, buf);
+#pragma unroll
+            for (int i = 0; i < V; ++i) s += buf[i];
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int c = lane * V; c < C; c += 64 * V) {
+            ld_vec<T>(xr + c, buf);                                         // L1 hit
+#pragma unroll
+            for (int i = 0; i < V; ++i) { const float d = buf[i] - mean; q += d * d; }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
+    }
+}
+
+// rows of exactly 1024 bf16 (the ViT-L width): the row stays in registers between the passes (as layernorm_rows_kernel<bf16, 2>)
+__global__ __launch_bounds__(256) void row_stats_1024_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int rows, float eps) {
+    constexpr int V = 8, NCH = 2, C = 1024;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int row = wave0; row < rows; row += nwaves) {
+        const bf16* xr = x + (int64_t)row * C;
+        float buf[NCH][V];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) ld_vec<bf16>(xr + (k * 64 + lane) * V, buf[k]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) s += buf[k][i];
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { const float d = buf[k][i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
+    }
+}
+
+extern "C" int setok_row_stats(void* stream, int dtype, const void* x, float* stats, int rows, int C, float eps) {
+    SETOK_CHECK_ARG(x && stats, "setok_row_stats: null operand");
+    SETOK_CHECK_ARG(rows >= 0 && C > 0 && C % 8 == 0, "setok_row_stats: C=%d must be a positive multiple of 8", C);
+    if (rows == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = min(cdiv(rows, 4), 256 * 8);
+    if (dtype == SETOK_BF16 && C == 1024) row_stats_1024_kernel<<<grid, 256, 0, s>>>((const bf16*)x, stats, rows, eps);
+    else if (dtype == SETOK_BF16) row_stats_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, stats, rows, C, eps);
+    else if (dtype == SETOK_F32) row_stats_kernel<float><<<grid, 256, 0, s>>>((const float*)x, stats, rows, C, eps);
+    else return setok_fail(SETOK_EINVAL, "setok_row_stats: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_row_stats");
+    return SETOK_OK;
+}
+
+// one wave per output row n of W (N, K)
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias, bf16* __restrict__ Wg, float* __restrict__ colsum,
+                                                      float* __restrict__ bias_folded, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float c = 0.f, bb = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(int64_t)n * K + k];
+        const bf16 wg = (bf16)(w * gamma[k]);
+        Wg[(int64_t)n * K + k] = wg;
+        c += (float)wg;
+        bb += w * beta[k];
+    }
+    c = wave_sum(c); bb = wave_sum(bb);
+    if (lane == 0) { colsum[n] = c; bias_folded[n] = (bias ? bias[n] : 0.f) + bb; }
+}
+
+extern "C" int setok_ln_fold(void* stream, const void* W, const float* gamma, const float* beta, const float* bias, void* w_gamma,
+                             float* w_colsum, float* bias_folded, int N, int K) {
+    SETOK_CHECK_ARG(W && gamma && beta && w_gamma && w_colsum && bias_folded && N > 0 && K > 0, "setok_ln_fold: bad argument");
+    ln_fold_kernel<<<cdiv(N, 4), 256, 0, (hipStream_t)stream>>>((const bf16*)W, gamma, beta, bias, (bf16*)w_gamma, w_colsum, bias_folded, N, K);
+    SETOK_CHECK_LAUNCH("setok_ln_fold");
+    return SETOK_OK;
+}
+
+// --------------------------------------------------------------------------------------------
 // Generic varlen attention: one wave per (query row, head).  Exact-softmax (max-subtracted, fp32).
 // This is the any-shape / parity-mode path (fp32, head dim 512 of the cluster encoders, ragged
 // segments); the bf16 ViT shape has its own MFMA kernel in attn_vit.hip.

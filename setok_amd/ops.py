@@ -107,6 +107,47 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Op
     return out
 
 
+# ---- LayerNorm folded into the consuming Linear (bf16 throughput mode; include/setok_hip.h explains the algebra) -------------------------
+def row_stats(x: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
+    """(rows, 2) fp32: {mean, 1 / sqrt(var + eps)} of every row of x, the statistics setok_layernorm computes, without writing a normalised copy."""
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    assert out.shape == (rows, 2) and out.dtype == torch.float32
+    _lib.call("setok_row_stats", _stream(), _code(x.dtype), _p(x), _p(out), rows, Cc, eps)
+    return out
+
+
+def ln_fold(w: Tensor, gamma: Tensor, beta: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """Once per weight load: (W' = bf16(gamma * W), c = W' 1, b' = b + W beta) for linear_ln."""
+    assert w.dtype == torch.bfloat16 and w.dim() == 2
+    N, K = w.shape
+    wg = torch.empty_like(w)
+    cs = torch.empty((N,), dtype=torch.float32, device=w.device)
+    bf = torch.empty((N,), dtype=torch.float32, device=w.device)
+    _lib.call("setok_ln_fold", _stream(), _p(w.contiguous()), _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(bias)), _p(wg), _p(cs), _p(bf), N, K)
+    return wg, cs, bf
+
+
+def linear_ln(a: Tensor, folded: Tuple[Tensor, Tensor, Tensor], stats: Tensor, act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """out = act(LayerNorm(a) @ W.T + b) from the raw rows `a`, their statistics and the folded weight triple of ln_fold."""
+    wg, cs, bf = folded
+    M, K = a.shape
+    N = wg.shape[0]
+    assert a.dtype == torch.bfloat16 and wg.shape[1] == K and stats.shape == (M, 2)
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("setok_linear_ln", _stream(), _p(a), K, _p(wg), _p(cs), _p(bf), _p(stats), _p(out), N, M, N, K, act)
+    if _PROFILE is not None:
+        e1.record()
+        alg = (M * K + N * K) * 2 + M * N * 2 + M * 8
+        _PROFILE.append(("gemm_bf16:" + ("plain", "quick_gelu", "gelu_erf")[act] + "+layernorm", 2.0 * M * N * K, e0, e1, float(alg)))
+    return out
+
+
 def attention(qkv: Tensor, H: int, Dh: int, scale: float, seg_len: int, seg_offsets: Optional[Tensor] = None,
               n_segs: int = 0, out: Optional[Tensor] = None) -> Tensor:
     """Block-diagonal attention.  Uniform segments of `seg_len` rows, or ragged ones given by the int32
@@ -175,8 +216,10 @@ def cluster_dpc_knn(x: Tensor, B: int, N: int, k: int, threshold: float, min_clu
     score = torch.empty((B, N), dtype=torch.float32, device=dev)
     index_down = torch.empty((B, N), dtype=torch.int64, device=dev)
     counts = torch.empty((B,), dtype=torch.int32, device=dev)
-    dist_ws = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-    vec_ws = torch.empty((B, 4, N), dtype=torch.float32, device=dev)
+    nd, nv = _lib.C.c_int64(0), _lib.C.c_int64(0)
+    _lib.call("setok_cluster_workspace", _code(x.dtype), B, N, Cc, _lib.C.byref(nd), _lib.C.byref(nv))
+    dist_ws = torch.empty((nd.value,), dtype=torch.float32, device=dev) if nd.value else None       # 0: the fused single-launch form
+    vec_ws = torch.empty((nv.value,), dtype=torch.float32, device=dev) if nv.value else None
     if noise is not None:
         noise = noise.to(device=dev, dtype=torch.float32).contiguous()
         assert noise.numel() == B * N

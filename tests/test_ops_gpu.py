@@ -394,3 +394,139 @@ def test_sort_gather_segment_mean():
         mean = ops.segment_mean(xs, seg.int().to(DEV), img.to(DEV)[B:], total).cpu()
         ref = torch.stack([x[perm][seg[s]:seg[s + 1]].double().mean(0) for s in range(total)])
         assert _rel_err(mean, ref) < tol
+
+
+# ---------------------------------------------------------------------------------------------
+# the single-launch, register-resident form of the clustering (bf16, N <= 256): every branch against the oracle on the same bf16-valued
+# features, and against the multi-kernel form of the same library (SETOK_CLUSTER_FUSED=0)
+# ---------------------------------------------------------------------------------------------
+FUSED_CASES = [
+    # N, C, planted regions, k, mcn, threshold, noise?, mask?
+    (256, 1024, 6, 64, 64, 0.5, False, False),      # cfg2 shape, dynamic-k on planted features
+    (256, 1024, 6, 64, 64, 1e9, False, False),      # fallback: the 64 best scores
+    (256, 1024, 9, 8, 64, 0.5, True, False),        # tie-break noise (tokenizer.py:91)
+    (256, 1024, 5, 8, 16, 0.5, False, True),        # token_mask (:84-86, :93-94)
+    (256, 1024, 5, 8, 16, 1e9, True, True),         # mask + noise + fallback
+    (196, 768, 7, 32, 32, 0.5, False, False),       # 14 x 14 grid (ViT-B/16), 768 channels: rows beyond N are padding inside the kernel
+    (196, 768, 7, 32, 32, 0.5, False, True),
+    (64, 64, 4, 8, 8, 0.5, False, False),           # one K-tile
+    (64, 128, 4, 48, 8, 0.5, True, False),
+    (64, 128, 4, 64, 8, 0.5, False, False),         # k == N: every density is the mean over the whole row
+    (16, 64, 3, 4, 4, 0.5, False, True),
+    (4, 64, 2, 2, 2, 0.5, False, False),
+    (1, 64, 1, 1, 1, 0.5, False, False),
+]
+
+
+@pytest.mark.parametrize("N,C,m,k,mcn,thr,with_noise,with_mask", FUSED_CASES)
+def test_cluster_fused_bf16_every_branch(N, C, m, k, mcn, thr, with_noise, with_mask):
+    B = 3
+    g = torch.Generator().manual_seed(N * 31 + C + k)
+    xs = torch.stack([O.planted_features(N, C, max(1, min(N, m)) + i, seed=90 + i) for i in range(B)]).bfloat16()
+    noise = torch.rand(B, N, generator=g) if with_noise else None
+    mask = None
+    if with_mask:
+        mask = (torch.rand(B, N, generator=g) > 0.3).float()
+        mask[:, 0] = 1.0
+    assert os.environ.get("SETOK_CLUSTER_FUSED") is None
+    idx, score, index_down, counts = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, k, thr, mcn, noise, mask)
+    os.environ["SETOK_CLUSTER_FUSED"] = "0"
+    try:
+        idx_m, score_m, down_m, counts_m = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, k, thr, mcn, noise, mask)
+    finally:
+        del os.environ["SETOK_CLUSTER_FUSED"]
+    n_same = 0
+    for i in range(B):
+        nz = None if noise is None else noise[i]
+        tm = None if mask is None else mask[i]
+        r = O.cluster_dpc_knn(xs[i].float(), k, thr, mcn, tm, nz)
+        # k == N: a density is the mean over the WHOLE row, tokens of one planted region tie to ~1e-7 and rounding of exp / the mean decides
+        # their order — beyond what a per-entry perturbation of d^2 models; widen it there
+        sens = O.cluster_sensitivity(xs[i].float(), k, thr, mcn, tm, nz, ulps=4.0 if k < N else 4096.0)
+        # the score envelope: the MFMA sums the C products of a Gram entry in its own order, sqrt(C) * 2^-24 |a||b| away from the CPU's order
+        # (tens of ulps of |a|^2 + |b|^2 at C = 1024), so near-tied densities of neighbouring planted tokens may order differently
+        sens_score = O.cluster_sensitivity(xs[i].float(), k, thr, mcn, tm, nz, ulps=64.0 if k < N else 4096.0)
+        L = int(counts[i])
+        assert int(idx[i].max()) < L and int(idx[i].min()) >= 0 and bool((index_down[i, L:] == -1).all())
+        O.check_cluster_parity(index_down[i, :L].cpu(), idx[i].cpu(), r.index_down, r.idx_cluster, sens)
+        try:
+            O.check_score(score[i].cpu(), sens_score)
+        except AssertionError as ex:
+            sens = sens_score
+            gs, ms, rs = score[i].cpu().double(), score_m[i].cpu().double(), r.score.reshape(-1).double()
+            bad = ((gs < sens["score_lo"] * (1 - 1e-3) - 1e-7) | (gs > sens["score_hi"] * (1 + 1e-3) + 1e-7)).nonzero().reshape(-1).tolist()
+            raise AssertionError(f"{ex}; image {i}; " + "; ".join(
+                f"tok {t}: fused {gs[t]:.6g} multi {ms[t]:.6g} oracle {rs[t]:.6g} env [{sens['score_lo'][t]:.6g}, {sens['score_hi'][t]:.6g}] "
+                f"mask {None if tm is None else float(tm[t])} rho {float(r.density[t]):.6g} delta {float(r.delta[t]):.6g}" for t in bad[:6]))
+        Lm = int(counts_m[i])
+        O.check_cluster_parity(down_m[i, :Lm].cpu(), idx_m[i].cpu(), r.index_down, r.idx_cluster, sens)
+        n_same += int(torch.equal(idx[i], idx_m[i]) and L == Lm)
+    print(f"fused vs multi-kernel: {n_same}/{B} images with identical integers")
+
+
+def test_cluster_fused_needs_no_workspace_and_is_deterministic():
+    from setok_amd import _lib
+    import ctypes
+    nd, nv = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    _lib.call("setok_cluster_workspace", ops.BF16, 256, 256, 1024, ctypes.byref(nd), ctypes.byref(nv))
+    assert nd.value == 0 and nv.value == 0                               # bf16, N <= 256: one launch, no distance matrix in memory
+    _lib.call("setok_cluster_workspace", ops.BF16, 128, 576, 1024, ctypes.byref(nd), ctypes.byref(nv))
+    assert nd.value == 128 * 576 * 576 and nv.value == 128 * 4 * 576
+    _lib.call("setok_cluster_workspace", ops.F32, 2, 256, 1024, ctypes.byref(nd), ctypes.byref(nv))
+    assert nd.value == 2 * 256 * 256
+    xs = torch.stack([O.planted_features(256, 1024, 5 + i, seed=120 + i) for i in range(64)]).bfloat16().to(DEV).reshape(-1, 1024)
+    a = ops.cluster_dpc_knn(xs, 64, 256, 64, 0.5, 64)
+    b = ops.cluster_dpc_knn(xs, 64, 256, 64, 0.5, 64)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    one = ops.cluster_dpc_knn(xs[5 * 256: 6 * 256], 1, 256, 64, 0.5, 64)
+    assert torch.equal(one[0][0], a[0][5]) and torch.equal(one[1][0], a[1][5]) and int(one[3][0]) == int(a[3][5])     # image alone == in the batch
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm folded into the consuming Linear (bf16 throughput mode)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,act", [(65792 // 8, 3072, 1024, 0), (65792 // 8, 4096, 1024, 1), (771, 3072, 1024, 0), (257, 4096, 1024, 1),
+                                       (300, 128, 64, 2), (5, 64, 192, 0), (8224, 1024, 1024, 2)])
+def test_linear_ln_equals_layernorm_then_linear(M, N, K, act):
+    """setok_row_stats + setok_ln_fold + setok_linear_ln against fp64 LayerNorm -> Linear -> activation on the same bf16 inputs, with a
+    mean and scale per row that make the rank-1 correction matter; and against the unfolded bf16 pipeline (separate setok_layernorm): the
+    folded form skips one bf16 rounding of the normalised activations, so it must not be further from fp64 than the unfolded one (+ margin)."""
+    g = torch.Generator().manual_seed(M + N + K + act)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + 1.5 * torch.randn(M, 1, generator=g)).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    gamma, beta, bias = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(N, generator=g)
+    xd, wd = x.to(DEV), w.to(DEV)
+    stats = ops.row_stats(xd, 1e-5)
+    mean = x.double().mean(1); var = x.double().var(1, unbiased=False)
+    assert _rel_err(stats[:, 0].cpu(), mean) < 1e-5 and _rel_err(stats[:, 1].cpu(), (var + 1e-5).rsqrt()) < 1e-5
+    folded = ops.ln_fold(wd, gamma.to(DEV), beta.to(DEV), bias.to(DEV))
+    assert torch.equal(folded[0].cpu(), (w.float() * gamma).bfloat16())
+    assert _rel_err(folded[1].cpu(), (w.float() * gamma).bfloat16().double().sum(1)) < 1e-5
+    assert _rel_err(folded[2].cpu(), bias.double() + w.double() @ beta.double()) < 1e-5
+    got = ops.linear_ln(xd, folded, stats, act=act).float().cpu()
+    unfolded = ops.linear(ops.layernorm(xd, gamma.to(DEV), beta.to(DEV), 1e-5), wd, bias.to(DEV), act=act).float().cpu()
+    y = (x.double() - mean[:, None]) * (var[:, None] + 1e-5).rsqrt() * gamma.double() + beta.double()
+    ref = y @ w.double().t() + bias.double()
+    if act == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    e_f, e_u = _rel_err(got, ref), _rel_err(unfolded, ref)
+    assert e_f < 8e-3 and e_f <= 1.5 * e_u + 1e-3, (e_f, e_u)
+
+
+def test_linear_ln_rows_do_not_depend_on_the_kernel():
+    """The persistent 256 x 256 kernel (a batch of images) and the 64 x 64 kernel (a few images) must give a row the same bits: same fragments
+    for the rank-2 start of the accumulators, same k order, same epilogue."""
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 65792 // 4, 3072, 1024
+    x = (torch.randn(M, K, generator=g) + 0.7).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+    gamma, beta, bias = (1.0 + 0.1 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
+    folded = ops.ln_fold(w, gamma, beta, bias)
+    stats = ops.row_stats(x, 1e-5)
+    for act in (0, 1):
+        big = ops.linear_ln(x, folded, stats, act=act)                       # 65 x 12 tiles: persistent (+ its 64 x 64 remainder launch)
+        for lo, n in ((0, 257), (5000, 771), (M - 300, 300)):
+            small = ops.linear_ln(x[lo:lo + n].contiguous(), folded, stats[lo:lo + n].contiguous(), act=act)
+            assert torch.equal(small, big[lo:lo + n]), (act, lo)
