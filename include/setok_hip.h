@@ -12,7 +12,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates
- *     nothing, and synchronises nothing — outputs and workspaces are caller-allocated;
+ *     nothing, and synchronises nothing — outputs and workspaces are caller-allocated (the context
+ *     entry points are the documented exception: they own the weights and read back the token counts);
  *   - `dtype` selects the activation/weight element type: SETOK_F32 (parity mode; fp32 MFMA,
  *     exact fma chains) or SETOK_BF16 (throughput mode; bf16 MFMA, fp32 accumulation);
  *     biases, LayerNorm affine parameters, scores and distances are always fp32;
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 2
+#define SETOK_ABI_VERSION 3
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -39,6 +40,64 @@ int setok_abi_version(void);
 const char* setok_last_error(void);
 /* Name of the device the library sees ("" if none), its CU count; both cheap, host-side only. */
 int setok_device_info(char* name_host, int name_cap, int* cu_count_host);
+
+/* Launch profiler (measurement aid, off by default; process-wide): between start and stop every setok_linear / setok_linear_ln /
+ * setok_cluster_dpc_knn call is bracketed by HIP events on its stream.  stop waits for them and returns the number of records written:
+ * kind 0 = bf16 GEMM, 1 = fp32 GEMM (work = FLOPs), 2 = clustering (work = Gram FLOPs); cls = act | residual << 2 | folded LayerNorm << 3;
+ * bytes = algorithmic bytes of the call; ms = event duration. */
+int setok_profile_start(void);
+int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* ms, int cap);
+
+/* ---- the whole path behind one call (host-language-neutral entry) -------------------------------------------------
+ * `SetokTokenizer.forward` (src/model/setok/tokenizer.py:157-182): tower (clip_encoder.py:50-62, HF CLIP ViT hidden_states[select_layer],
+ * feature_select :40-48) -> + PositionalEncoding2D (:164-168) -> cluster_dpc_knn (:174) -> group_encoding (:177-178) -> inter_encoder
+ * (:179) -> out (:180).  A context owns device copies of the weights in compute layout; setok_encode runs the path on the caller's
+ * stream into caller-allocated buffers.  These are the only entry points that allocate (create / load / ready) or synchronise:
+ * setok_encode waits ONCE for the stream, after the clustering, to read the B per-image token counts that size the ragged stages
+ * (the same single host read the reference's data-dependent shapes force on any implementation).
+ * Contexts are independent: no global mutable state, one context per (device, stream) in use at a time. */
+typedef struct setok_ctx setok_ctx;
+
+typedef struct setok_config {
+    /* tower: the HF CLIP vision config behind clip_encoder.py:35 */
+    int image_size, patch_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads;
+    float layer_norm_eps;
+    int select_layer;            /* mm_vision_select_layer (clip_encoder.py:41): index into hidden_states, negative from the end */
+    int select_cls_patch;        /* mm_vision_select_feature: 0 = 'patch' (drop the class token, :43), 1 = 'cls_patch' */
+    /* head: ctor kwargs of SetokTokenizer (tokenizer.py:14-34); hidden_dim == tower hidden_size */
+    int token_feat_dim, nheads, dim_feedforward, inner_cluster_layers, intra_cluster_layers, min_cluster_num;
+    float threshold;
+    int dtype;                   /* SETOK_BF16 (throughput mode) or SETOK_F32 (parity mode) */
+    int fold_layernorm;          /* bf16 only: fold layer_norm1 / layer_norm2 of the tower into the q|k|v / fc1 GEMMs */
+} setok_config;
+
+int setok_create(const setok_config* cfg, setok_ctx** out);
+void setok_destroy(setok_ctx* ctx);
+const char* setok_ctx_error(const setok_ctx* ctx);
+
+/* One parameter by its name in the reference's state dict (`image_feature_encoder.vision_tower.` + HF CLIPVisionModel names, with or
+ * without HF 4.x's `vision_model.`; `inner_encoder.*`, `inter_encoder.*`, `out.*`), plus `position_embedding.table`: the (N, C)
+ * PositionalEncoding2D table of module.py:118-146 in the compute dtype (the reference builds it on the host in fp32 and casts; passing it
+ * keeps it bit-identical to the host's).  `ptr` is a DEVICE pointer to a dense tensor of `dtype` and `shape`; the data is copied
+ * (matrices to the compute dtype, vectors to fp32) on `stream`. */
+int setok_load_weight(setok_ctx* ctx, void* stream, const char* name, const void* ptr, int dtype, const int64_t* shape, int ndim);
+
+/* After the last setok_load_weight: checks that every parameter the configuration needs is there (the error names the first missing
+ * one) and builds the fused q|k|v matrices, the padded patch matrix and the folded LayerNorm operands. */
+int setok_weights_ready(setok_ctx* ctx, void* stream);
+
+/* Bytes of 256-byte-aligned device workspace setok_encode needs for a batch of B images. */
+int64_t setok_encode_workspace_bytes(const setok_ctx* ctx, int B);
+
+/* images (B, 3, image_size, image_size) in the compute dtype -> tokens: packed (sum_b L_b, token_feat_dim) rows, image b owning rows
+ * [sum_{b' < b} L_b', + L_b) (capacity B * N rows), counts (B) int32 on the device and in `counts_host`, idx_cluster (B, N) int64,
+ * score (B, N) fp32, index_down (B, N) int64 (-1 padded).  k / threshold == 0 select the configured defaults (the reference's
+ * truthiness rule, tokenizer.py:171-172); noise / token_mask as in setok_cluster_dpc_knn (NULL = none).  The optional stage_* outputs
+ * receive pointers INTO the workspace (valid until its next use): x = features + positions (B*N, C), group (sum L, C), inter (sum L, C). */
+int setok_encode(setok_ctx* ctx, void* stream, const void* images, int B, int k, float threshold, const float* noise,
+                 const float* token_mask, void* workspace, int64_t workspace_bytes, void* tokens, int32_t* counts,
+                 int64_t* idx_cluster, float* score, int64_t* index_down, int32_t* counts_host, int64_t* total_tokens_host,
+                 void** stage_x, void** stage_group, void** stage_inter);
 
 /* ---- dense layers ------------------------------------------------------------------------ */
 
@@ -106,18 +165,20 @@ int setok_vit_assemble(void* stream, int dtype, const void* patch_embed, const v
  * so the GEMM reads the raw residual stream h and no normalised copy of it is ever written.  The fp32 parity mode keeps the separate
  * setok_layernorm. */
 
-/* stats[r] = {mean, rstd = 1 / sqrt(var + eps)} of row r (rows x C, `dtype`), two-pass fp32 statistics in setok_layernorm's order. */
+/* stats row r (8 floats): [0], [1] the compact activation-side MFMA fragment of (-mean_r, 1 / rstd_r) (two bf16 pairs: two-way splits),
+ * [4] rstd_r = 1 / sqrt(var + eps), [5] mean_r, the rest 0.  Two-pass fp32 statistics in setok_layernorm's order; rows x C, `dtype`. */
 int setok_row_stats(void* stream, int dtype, const void* x, float* stats, int rows, int C, float eps);
 
 /* Once per weight load: W (N, K) bf16, gamma / beta (K) fp32, bias (N) fp32 or NULL ->
- * w_gamma (N, K) bf16, w_colsum (N) fp32, bias_folded (N) fp32. */
+ * w_gamma (N, K) bf16, w_colsum (N) fp32, bias_folded (N) fp32, col_frag (N, 4) fp32-sized words: the weight-side MFMA fragment of
+ * (w_colsum[n], bias_folded[n]) as 8 bf16. */
 int setok_ln_fold(void* stream, const void* W, const float* gamma, const float* beta, const float* bias, void* w_gamma,
-                  float* w_colsum, float* bias_folded, int N, int K);
+                  float* w_colsum, float* bias_folded, float* col_frag, int N, int K);
 
-/* C[M,N] = act(LN(A)[M,K] . W[N,K]^T + bias) from the folded operands above and the row statistics of A (bf16 in, bf16 out;
+/* C[M,N] = act(LN(A)[M,K] . W[N,K]^T + bias) from w_gamma / col_frag of setok_ln_fold and the row statistics of A (bf16 in, bf16 out;
  * K % 64 == 0, N % 64 == 0, lda / ldc multiples of 8). */
-int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* w_colsum, const float* bias_folded,
-                    const float* row_stats, void* C, int64_t ldc, int M, int N, int K, int act);
+int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* col_frag, const float* row_stats,
+                    void* C, int64_t ldc, int M, int N, int K, int act);
 
 /* ---- SeTok head glue --------------------------------------------------------------------- */
 

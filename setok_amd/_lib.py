@@ -11,19 +11,38 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SETOK_HIP_LIB") or os.path.join(_HERE, "libsetok_hip.so")   # SETOK_HIP_LIB: another build of the same ABI (A/B runs)
 
 F32, BF16 = 0, 1
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
-_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+class SetokConfig(C.Structure):
+    """`setok_config` of include/setok_hip.h, field for field."""
+    _fields_ = [("image_size", _i), ("patch_size", _i), ("hidden_size", _i), ("intermediate_size", _i), ("num_hidden_layers", _i),
+                ("num_attention_heads", _i), ("layer_norm_eps", _f), ("select_layer", _i), ("select_cls_patch", _i),
+                ("token_feat_dim", _i), ("nheads", _i), ("dim_feedforward", _i), ("inner_cluster_layers", _i), ("intra_cluster_layers", _i),
+                ("min_cluster_num", _i), ("threshold", _f), ("dtype", _i), ("fold_layernorm", _i)]
+
+
+RESTYPES = {"setok_last_error": C.c_char_p, "setok_ctx_error": C.c_char_p, "setok_encode_workspace_bytes": _i64, "setok_destroy": None}
 
 # name -> argtypes; mirrors include/setok_hip.h declaration by declaration
 SIGNATURES = {
+    "setok_profile_start": [],
+    "setok_profile_stop": [_vp, _vp, _vp, _vp, _vp, _i],
+    "setok_create": [C.POINTER(SetokConfig), C.POINTER(_vp)],
+    "setok_destroy": [_vp],
+    "setok_ctx_error": [_vp],
+    "setok_load_weight": [_vp, _vp, C.c_char_p, _vp, _i, C.POINTER(_i64), _i],
+    "setok_weights_ready": [_vp, _vp],
+    "setok_encode_workspace_bytes": [_vp, _i],
+    "setok_encode": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(_i64),
+                     C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "setok_abi_version": [],
     "setok_last_error": [],
     "setok_device_info": [C.c_char_p, _i, C.POINTER(_i)],
     "setok_linear": [_vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i64, _i64, _i64],
     "setok_row_stats": [_vp, _i, _vp, _vp, _i, _i, _f],
-    "setok_ln_fold": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
-    "setok_linear_ln": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i],
+    "setok_ln_fold": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
+    "setok_linear_ln": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i],
     "setok_layernorm": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f],
     "setok_activation": [_vp, _i, _vp, _vp, _i64, _i],
     "setok_attention": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f],
@@ -73,7 +92,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "setok_last_error" else _i
+        fn.restype = RESTYPES.get(name, _i)
     _lib = lib
     return lib
 

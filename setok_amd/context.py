@@ -1,0 +1,110 @@
+"""`setok_ctx` of the C ABI behind a small Python object: the whole `SetokTokenizer.forward` (tower -> positions -> clustering -> cluster
+encoders -> out) as ONE library call (`setok_encode`, csrc/context.hip) on torch-allocated buffers.
+
+The context is the form of the path a host in ANY language binds (include/setok_hip.h: setok_create / setok_load_weight /
+setok_weights_ready / setok_encode): this file only hands over the module's parameters by their reference state-dict names and
+allocates the outputs.  tests/test_context_gpu.py drives the same entry points with nothing but ctypes and numpy."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .ops import _code, _stream
+
+
+def _skip(name: str) -> bool:
+    if name.endswith("inv_freq") or ".post_layernorm." in name:
+        return True
+    if ".layers." in name and not name.startswith("image_feature_encoder."):
+        return name.split(".layers.")[1].split(".")[1] == "0"                  # `layers.{i}.0.*` alias norm1 (module.py:87-88)
+    return False
+
+
+class EncodeContext:
+    def __init__(self, tok, fold_layernorm: bool = True):
+        tower = tok.image_feature_encoder
+        cfg, dev, dt = tower.config, tok.device, tok.dtype
+        if dev.type != "cuda":
+            raise _lib.SetokHipError("the SeTok path runs on the GPU only (there is no CPU fallback): move the module to a cuda device")
+        blk = tok.inner_encoder
+        sc = _lib.SetokConfig(
+            image_size=cfg.image_size, patch_size=cfg.patch_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+            num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads, layer_norm_eps=cfg.layer_norm_eps,
+            select_layer=tower.select_layer, select_cls_patch={"patch": 0, "cls_patch": 1}[tower.select_feature],
+            token_feat_dim=tok.token_feat_dim, nheads=blk.num_heads, dim_feedforward=blk.mlp.fc1.out_features,
+            inner_cluster_layers=len(tok.inner_encoder.layers), intra_cluster_layers=len(tok.inter_encoder.layers),
+            min_cluster_num=tok.min_cluster_num, threshold=float(tok.threshold), dtype=_code(dt), fold_layernorm=1 if fold_layernorm else 0)
+        self.handle = C.c_void_p()
+        _lib.call("setok_create", C.byref(sc), C.byref(self.handle))
+        self.device, self.dtype = dev, dt
+        self.N = (cfg.image_size // cfg.patch_size) ** 2
+        self.C, self.D = cfg.hidden_size, tok.token_feat_dim
+        self._ws = {}
+        st = _stream()
+        with torch.no_grad():
+            named = dict(tok.state_dict())
+            g = int(self.N ** 0.5)
+            named["position_embedding.table"] = tok.position_embedding.table(g, g, dt, dev)
+            for name, t in named.items():
+                if _skip(name):
+                    continue
+                t = t.detach()
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                t = t.to(dev).contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                _lib.call("setok_load_weight", self.handle, st, name.encode(), t.data_ptr(), _code(t.dtype), shape, t.dim())
+            _lib.call("setok_weights_ready", self.handle, st)
+        torch.cuda.current_stream().synchronize()                     # the staging copies above read tensors that may die now
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().setok_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def encode(self, images: torch.Tensor, k: Optional[int] = None, threshold: Optional[float] = None, noise=None, token_mask=None,
+               return_stages: bool = False):
+        """images (B, 3, H, W) on the context's device -> (packed tokens (sum L_i, D), counts list, idx_cluster (B, N) int64,
+        score (B, N) fp32, index_down (B, N) int64[, stages])."""
+        B, N, dev = images.shape[0], self.N, self.device
+        x = images.to(device=dev, dtype=self.dtype).contiguous()
+        nbytes = _lib.load().setok_encode_workspace_bytes(self.handle, B)
+        ws = self._ws.get(B)
+        if ws is None or ws.numel() < nbytes:
+            self._ws = {B: torch.empty(nbytes, dtype=torch.uint8, device=dev)}            # one batch size cached: the workspace is the activations' size
+            ws = self._ws[B]
+        tokens = torch.empty((B * N, self.D), dtype=self.dtype, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        idx = torch.empty((B, N), dtype=torch.int64, device=dev)
+        score = torch.empty((B, N), dtype=torch.float32, device=dev)
+        index_down = torch.empty((B, N), dtype=torch.int64, device=dev)
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            assert noise.numel() == B * N
+        if token_mask is not None:
+            token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
+            assert token_mask.numel() == B * N
+        counts_h = (C.c_int32 * B)()
+        total = C.c_int64(0)
+        sx, sg, si = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.call("setok_encode", self.handle, _stream(), x.data_ptr(), B, int(k) if k else 0, float(threshold) if threshold else 0.0,
+                  None if noise is None else noise.data_ptr(), None if token_mask is None else token_mask.data_ptr(),
+                  ws.data_ptr(), ws.numel(), tokens.data_ptr(), counts.data_ptr(), idx.data_ptr(), score.data_ptr(), index_down.data_ptr(),
+                  counts_h, C.byref(total), C.byref(sx) if return_stages else None, C.byref(sg) if return_stages else None,
+                  C.byref(si) if return_stages else None)
+        cl = list(counts_h)
+        out = (tokens[: total.value], cl, idx, score, index_down)
+        if not return_stages:
+            return out
+        es = tokens.element_size()
+
+        def view(ptr, rows):                                          # a stage lives inside the workspace tensor
+            off = ptr.value - ws.data_ptr()
+            return ws[off: off + rows * self.C * es].view(self.dtype).reshape(rows, self.C).clone()
+        return out + (dict(x=view(sx, B * N), group=view(sg, total.value), inter=view(si, total.value), index_down=index_down, counts=cl),)

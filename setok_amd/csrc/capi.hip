@@ -34,3 +34,53 @@ extern "C" int setok_device_info(char* name_host, int name_cap, int* cu_count_ho
     if (cu_count_host) *cu_count_host = p.multiProcessorCount;
     return SETOK_OK;
 }
+
+// ---- launch profiler ---------------------------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { int kind, cls; double work, bytes; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+volatile int g_prof_on = 0;
+}  // namespace
+
+bool setok_prof_on() { return g_prof_on != 0; }
+
+int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes) {
+    ProfRec r{kind, cls, work, bytes, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+    (void)hipEventRecord(r.e0, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+
+void setok_prof_end(hipStream_t s, int index) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (index >= 0 && index < (int)g_prof.size()) (void)hipEventRecord(g_prof[index].e1, s);
+}
+
+extern "C" int setok_profile_start(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = 1;
+    return SETOK_OK;
+}
+
+// Stops recording, waits for the recorded launches and writes up to `cap` records; returns the number of records (or a negative code).
+extern "C" int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* ms, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = 0;
+    int n = 0;
+    for (auto& r : g_prof) {
+        float t = 0.f;
+        const bool ok = hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess;
+        if (ok && n < cap && kind && cls && work && bytes && ms) { kind[n] = r.kind; cls[n] = r.cls; work[n] = r.work; bytes[n] = r.bytes; ms[n] = t; ++n; }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    const int total = (int)g_prof.size();
+    g_prof.clear();
+    return n < total && cap >= total ? -1 : n;
+}

@@ -356,14 +356,21 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
         bool done0 = false, done1 = false;
         for (int bit = 30; bit >= 0; --bit) {
             const unsigned c0 = T0 | (1u << bit), c1 = T1 | (1u << bit);
+            // #values < candidate: the sign bit of (pattern - candidate) (both below 2^31) is shifted into a 32-bit register per element
+            // (v_sub + v_alignbit: no carry flag, hence none of the wait states a v_cmp / v_addc chain needs) and popcounted per 32 elements
             int q0 = 0, q1 = 0;
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
+            for (int th = 0; th < 2; ++th) {
+                unsigned w0 = 0, w1 = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    q0 += __float_as_uint(val(0, t, e)) < c0;
-                    q1 += __float_as_uint(val(1, t, e)) < c1;
-                }
+                for (int t = th * 8; t < th * 8 + 8; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        w0 = __builtin_amdgcn_alignbit(w0, __float_as_uint(val(0, t, e)) - c0, 31);
+                        w1 = __builtin_amdgcn_alignbit(w1, __float_as_uint(val(1, t, e)) - c1, 31);
+                    }
+                q0 += __builtin_popcount(w0); q1 += __builtin_popcount(w1);
+            }
             q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
             q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
             if (!done0) { if (q0 <= k - 1) T0 = c0; else if (q0 == k) { T0 = c0; done0 = true; } }
@@ -384,9 +391,12 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
         s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
         q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
         q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+        // values tied AT the k-th place (q < k) enter with the k-th value; a row finished early has q == k and its T is a candidate, not a
+        // value (its square may overflow: 0 * inf): no tie term then
         const float kth0 = __uint_as_float(T0), kth1 = __uint_as_float(T1);
-        float rho0 = expf(-((s0 + (float)(k - q0) * (kth0 * kth0)) / (float)k));
-        float rho1 = expf(-((s1 + (float)(k - q1) * (kth1 * kth1)) / (float)k));
+        const float tie0 = q0 < k ? (float)(k - q0) * (kth0 * kth0) : 0.f, tie1 = q1 < k ? (float)(k - q1) * (kth1 * kth1) : 0.f;
+        float rho0 = expf(-((s0 + tie0) / (float)k));
+        float rho1 = expf(-((s1 + tie1) / (float)k));
         if (g.noise) {
             if (row0 < N) rho0 += g.noise[(int64_t)b * N + row0] * 1e-6f;
             if (row1 < N) rho1 += g.noise[(int64_t)b * N + row1] * 1e-6f;
@@ -729,6 +739,8 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * N;
     const float sqrtC = (float)sqrt((double)C);
+    // algorithmic bytes: x read once; idx_cluster (int64), score (fp32), index_down (int64, <= N) written
+    SetokProfScope prof(s, SETOK_PROF_CLUSTER, 0, 2.0 * B * (double)N * N * C, (double)B * ((double)N * C * (dtype == SETOK_BF16 ? 2 : 4) + N * 8.0 + N * 4.0 + N * 8.0));
     if (dtype == SETOK_BF16 && C % 64 == 0 && N <= FN && !fused_disabled()) {
         // the whole call in one launch, one workgroup per image, no workspace (the BASELINE configuration)
         static SetokDeviceOnce once_f;

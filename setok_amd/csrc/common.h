@@ -31,6 +31,19 @@ int setok_fail(int code, const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- optional launch profiler (capi.hip): HIP events on the launch stream around the GEMM and clustering entry points ------------------
+// Off by default (one relaxed load per call).  bench.py switches it on around its timed region: `roofline.achieved` is the algorithmic
+// work of these launches / their event durations, measured where the launches really happen — inside the library, whichever host calls it.
+enum { SETOK_PROF_GEMM_BF16 = 0, SETOK_PROF_GEMM_F32 = 1, SETOK_PROF_CLUSTER = 2 };
+bool setok_prof_on();
+int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes);    // cls: act | residual << 2 | layernorm << 3; returns the record's index
+void setok_prof_end(hipStream_t s, int index);
+struct SetokProfScope {                              // scopes may nest (the fp32 clustering calls setok_linear for its Gram matrices)
+    hipStream_t s; int idx;
+    SetokProfScope(hipStream_t s_, int kind, int cls, double work, double bytes) : s(s_), idx(setok_prof_on() ? setok_prof_begin(s_, kind, cls, work, bytes) : -1) {}
+    ~SetokProfScope() { if (idx >= 0) setok_prof_end(s, idx); }
+};
+
 // ---- per-device one-time setup (host) ---------------------------------------------------------
 // hipFuncSetAttribute (dynamic-LDS limit) is a property of (function, DEVICE); a process-wide `static bool` would skip it on a second
 // device of the same process and races between threads.  One atomic bit per device: the setup is idempotent, so two threads doing it at
@@ -132,6 +145,36 @@ __device__ inline float gelu_erf_fast(float x) {
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     const float half_tail = 0.5f * poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // 0.5 * (1 - erf(|z|))
     return x * (x >= 0.f ? 1.0f - half_tail : half_tail);
+}
+
+// ---- LayerNorm folded into the consuming GEMM: the rank-2 start of the accumulators as two-way bf16 splits (gemm_persist.hip) ----------
+__device__ inline void split2(float x, bf16& hi, bf16& lo) {           // x = hi + lo + O(2^-16 |x|), both by truncation
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    hi = __builtin_bit_cast(bf16, (unsigned short)(u >> 16));
+    const float r = x - __builtin_bit_cast(float, u & 0xffff0000u);
+    lo = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r) >> 16));
+}
+__device__ inline bf16x8 ln_col_frag(float c, float b) {                // the W-side operand's k-slots 0-7 for one output column
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16)0.0f;
+    {
+        bf16 ch, cl, bh, bl;
+        split2(c, ch, cl); split2(b, bh, bl);
+        f[0] = ch; f[1] = ch; f[2] = cl; f[3] = cl; f[4] = bh; f[5] = bh; f[6] = bl; f[7] = bl;
+    }
+    return f;
+}
+__device__ inline bf16x8 ln_row_frag(float mean, float rstd) {          // the activation-side operand's k-slots 0-7 for one output row
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16)0.0f;
+    {
+        bf16 mh, ml, sh, sl;
+        split2(-mean, mh, ml); split2(1.0f / rstd, sh, sl);
+        f[0] = mh; f[1] = ml; f[2] = mh; f[3] = ml; f[4] = sh; f[5] = sl; f[6] = sh; f[7] = sl;
+    }
+    return f;
 }
 
 __device__ inline float act_apply(float v, int act) {

@@ -241,6 +241,9 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
     if (M == 0) return SETOK_OK;
     GemmArgs g{A, W, bias, residual, C, lda, ldc, strideA, strideW, strideC, M, N, K, act};
     hipStream_t s = (hipStream_t)stream;
+    const double es_in = dtype == SETOK_BF16 ? 2.0 : 4.0, es_out = out_dtype == SETOK_BF16 ? 2.0 : 4.0;
+    SetokProfScope prof(s, dtype == SETOK_BF16 ? SETOK_PROF_GEMM_BF16 : SETOK_PROF_GEMM_F32, act | (residual ? 4 : 0), 2.0 * M * N * K * batch,
+                        batch * (((double)M * K + (double)N * K) * es_in + (double)M * N * es_out * (residual ? 2 : 1)));   // A, W (+ residual) read once, C written once
     {
         static const bool env_small = [] { const char* e = getenv("SETOK_GEMM_SMALL_TILES"); return e && e[0] == '1'; }();
         g_force_small_tiles = env_small;
@@ -282,17 +285,18 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
 
 // LayerNorm folded into the consuming Linear (bf16 throughput mode; gemm_persist.hip explains the algebra).  Same kernel choice as
 // setok_linear makes for a bf16 -> bf16 problem, so a row's result does not depend on the batch it is computed in.
-extern "C" int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* w_colsum, const float* bias_folded,
-                               const float* row_stats, void* C, int64_t ldc, int M, int N, int K, int act) {
-    SETOK_CHECK_ARG(A && w_gamma && w_colsum && bias_folded && row_stats && C, "setok_linear_ln: null operand");
+extern "C" int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* col_frag, const float* row_stats,
+                               void* C, int64_t ldc, int M, int N, int K, int act) {
+    SETOK_CHECK_ARG(A && w_gamma && col_frag && row_stats && C, "setok_linear_ln: null operand");
     SETOK_CHECK_ARG(M >= 0 && N > 0 && K > 0, "setok_linear_ln: bad shape M=%d N=%d K=%d", M, N, K);
     SETOK_CHECK_ARG(act >= SETOK_ACT_NONE && act <= SETOK_ACT_GELU_ERF, "setok_linear_ln: bad act %d", act);
     SETOK_CHECK_ARG(K % BK == 0 && N % 64 == 0 && lda >= K && ldc >= N && lda % 8 == 0 && ldc % 8 == 0,
                     "setok_linear_ln: needs K %% 64 == 0, N %% 64 == 0, 16-byte aligned rows (M=%d N=%d K=%d)", M, N, K);
     if (M == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
+    SetokProfScope prof(s, SETOK_PROF_GEMM_BF16, act | 8, 2.0 * M * N * K, ((double)M * K + (double)N * K) * 2.0 + (double)M * N * 2.0 + (double)M * 32.0);
     static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();
     if (K >= 192 && cdiv(M, 256) * cdiv(N, 256) >= persist_min)
-        return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, bias_folded, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, w_colsum);
-    return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, bias_folded, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, w_colsum);
+        return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag);
+    return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag);
 }

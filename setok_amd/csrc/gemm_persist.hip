@@ -42,8 +42,8 @@ struct PArgs {
     float* Cf;                   // F32B variant: fp32 output, `nbatch` independent problems (split-K partial products of a weight gradient)
     int64_t sA, sW, sC;          //   element strides between the batch members
     int nbatch;
-    const float* ln_stats;       // LNK variant: per row of A {mean, rstd} (setok_row_stats): the LayerNorm folded into this GEMM
-    const float* ln_colsum;      //   c[n] = sum_k W'[n][k], W' = bf16(gamma * W);  `bias` then holds b'[n] = b[n] + sum_k W[n][k] beta[k]
+    const float* ln_stats;       // LNK variant: per row of A 8 floats {row fragment (4 dwords), rstd, mean, 0, 0} (setok_row_stats): the LayerNorm folded into this GEMM
+    const float* ln_colsum;      //   per column 4 dwords: the column fragment of c[n] = sum_k W'[n][k] and b'[n] = b[n] + sum_k W[n][k] beta[k] (setok_ln_fold)
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -69,33 +69,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // and the epilogue multiplies by rstd_r.  Both GEMM kernels build the fragments with the functions below, so a row's result does not
 // depend on which kernel produced it.
 // --------------------------------------------------------------------------------------------
-__device__ inline void split2(float x, bf16& hi, bf16& lo) {           // x = hi + lo + O(2^-16 |x|), both by truncation
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    hi = __builtin_bit_cast(bf16, (unsigned short)(u >> 16));
-    const float r = x - __builtin_bit_cast(float, u & 0xffff0000u);
-    lo = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r) >> 16));
-}
-__device__ inline bf16x8 ln_col_frag(float c, float b, int g4) {        // the W-side operand: output column (lane & 15); k-slots 0-7 live in lanes 0-15
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (bf16)0.0f;
-    if (g4 == 0) {
-        bf16 ch, cl, bh, bl;
-        split2(c, ch, cl); split2(b, bh, bl);
-        f[0] = ch; f[1] = ch; f[2] = cl; f[3] = cl; f[4] = bh; f[5] = bh; f[6] = bl; f[7] = bl;
-    }
-    return f;
-}
-__device__ inline bf16x8 ln_row_frag(float mean, float rstd, int g4) {  // the activation-side operand: output row (lane & 15)
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (bf16)0.0f;
-    if (g4 == 0) {
-        bf16 mh, ml, sh, sl;
-        split2(-mean, mh, ml); split2(1.0f / rstd, sh, sl);
-        f[0] = mh; f[1] = ml; f[2] = mh; f[3] = ml; f[4] = sh; f[5] = sl; f[6] = sh; f[7] = sl;
-    }
-    return f;
+// The fragments themselves (8 bf16 = 16 bytes per row / per column) are written once by setok_row_stats / setok_ln_fold (common.h:
+// ln_row_frag / ln_col_frag); a GEMM lane only loads them — the k-slots 0-7 of a 16x16x32 operand live in lanes 0-15, the other lanes hold zeros.
+__device__ inline bf16x8 ln_frag_lane(const f32x4 raw, int g4) {
+    f32x4 v = raw;
+    if (g4 != 0) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+    return __builtin_bit_cast(bf16x8, v);
 }
 
 template <int N_>
@@ -127,6 +106,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     constexpr int MT = 8, NT = 4;                           // 16 x 16 MFMA tiles per wave: 8 along M (128 rows) x 4 along N (64 columns)
     constexpr int NL = 8;                          // LDS-DMA ops per lane per K-tile
     constexpr int NSTORE = WR / 8;                 // 16-byte stores per lane per (interior) tile
+    constexpr int NLN = LNK ? 5 : 0;               // LNK: loads per lane per tile (one column fragment, two compact row fragments, two rstd)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -196,22 +176,30 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     // holds the bias split into three bf16 parts (hi + mid + lo = the fp32 value exactly) against a fragment of ones: acc = 0 + hi + mid + lo
     // is exact, so the arithmetic (bias first, then the products in ascending k) is unchanged bit for bit.
     float nb[NT];
-    float ncs[LNK ? NT : 1];                        // LNK: column sums of W' for the same columns,
-    float nmean[LNK ? MT : 1], nrstd[LNK ? MT : 1]; //      {mean, rstd} of the rows (t * 16 + l15 of the wave's 128) of the NEXT tile
+    // LNK: a lane fetches ONE column fragment (16 bytes: column g4 * 16 + l15 of the wave's 64) and the compact form (8 bytes) of TWO row
+    // fragments (rows (2 g4 + i) * 16 + l15 of the wave's 128) — 8 registers instead of 48 for the tile's 12 fragments; at the tile's start the
+    // lanes that feed the MFMA's k-slots 0-7 (lanes 0-15) collect them from the other 16-lane groups with ds_bpermute.
+    f32x4 ncw; float2 nrw[2];
+    float nrs[2], ers[2];                          // rstd of the same two rows: of the NEXT tile (fetched with the fragments) / of the CURRENT one
     auto load_bias = [&](int n0_, int m0_) {
-        if constexpr (!F32B) {
+        if constexpr (!F32B && !LNK) {
             const float* bp = g.bias ? g.bias + min(n0_ + wn * 64, g.N - 64) : g.zero_bias;
 #pragma unroll
             for (int j = 0; j < NT; ++j) nb[j] = bp[j * 16 + l15];
         }
+    };
+    // They are fetched in the MIDDLE of the previous tile's epilogue (after its second pass), so that their L2 round trip (1-2 us under
+    // load) has the rest of the epilogue to complete: fetched at the tile's own start the round trip was exposed (-7 % on the qkv shape);
+    // as 12 full fragments per lane a tile ahead they spilled 40-64 registers (-17 %).  NLN extra entries sit in the vector-memory queue
+    // between the stores of passes 1 and 2: the counted waits at the next tile's start allow for them.
+    auto load_ln_frags = [&](int n0_, int m0_) {
         if constexpr (LNK) {
-            const float* cp = g.ln_colsum + min(n0_ + wn * 64, g.N - 64);
+            ncw = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)(min(n0_ + wn * 64, g.N - 64) + g4 * 16 + l15));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ncs[j] = cp[j * 16 + l15];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const float2 st = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (int64_t)min(m0_ + wm * WR + t * 16 + l15, g.M - 1));
-                nmean[t] = st.x; nrstd[t] = st.y;
+            for (int i = 0; i < 2; ++i) {
+                const float* st = g.ln_stats + 8 * (int64_t)min(m0_ + wm * WR + (2 * g4 + i) * 16 + l15, g.M - 1);
+                nrw[i] = *reinterpret_cast<const float2*>(st);
+                nrs[i] = st[4];
             }
         }
     };
@@ -220,6 +208,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     if (!tile_of(0, m0, n0, bz)) return;
     set_src(m0, n0, bz);
     load_bias(n0, m0);
+    load_ln_frags(n0, m0);                         // (the first tile's: ahead of everything)
     issue_ktile(0, 0);
     issue_ktile(1, TK);
     int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
@@ -283,23 +272,35 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         };
         using yes = std::true_type; using no = std::false_type;
 
-        // In flight at this point, oldest first: K-tile 0, K-tile 1, the previous epilogue's stores (nk >= 3: dispatch condition).
+        // In flight at this point, oldest first: K-tile 0, K-tile 1, the previous epilogue's stores (nk >= 3: dispatch condition)
+        // [LNK: + the NLN fragment loads of this tile between them].
         {
             const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-            if (pend == NSTORE) wait_vm<NSTORE + NL>(); else wait_vm<NL>();       // K-tile 0 has landed
+            if (pend == NSTORE) wait_vm<NSTORE + NL + NLN>(); else wait_vm<NL>();       // K-tile 0 has landed
             if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
         }
         s_barrier_lgkm();
         if constexpr (LNK) {   // ---- accumulators start at (-mean_r) c_n + (1 / rstd_r) b'_n ---------------------------------------------------
+            auto from_group = [&](float v, int grp) {              // lane (l15, *) reads lane (l15, grp)
+                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l15 + 16 * grp) << 2, __builtin_bit_cast(int, v)));
+            };
             bf16x8 cfr[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) cfr[j] = ln_col_frag(ncs[j], nb[j], g4);
+            for (int j = 0; j < NT; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = from_group(ncw[e], j);
+                cfr[j] = ln_frag_lane(v, g4);
+            }
+            ers[0] = nrs[0]; ers[1] = nrs[1];                     // kept for this tile's epilogue: a load there would wait for the operand DMA in flight
             f32x4 z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = 0.f;
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const bf16x8 rfr = ln_row_frag(nmean[t], nrstd[t], g4);
+                const float d0 = from_group(nrw[t & 1].x, t >> 1), d1 = from_group(nrw[t & 1].y, t >> 1);
+                const f32x4 v = {d0, d0, d1, d1};                  // (-mean hi, lo) twice, (1 / rstd hi, lo) twice
+                const bf16x8 rfr = ln_frag_lane(v, g4);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
             }
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         multiply(no{}, false, 0);                                                 // K-tile 1 was requested at the previous tile boundary
         {
             const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
-            if (pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>();             // K-tile 1 has landed; the stores may still fly
+            if (pend == NSTORE) wait_vm<NSTORE + NLN>(); else wait_vm<0>();       // K-tile 1 has landed; the stores may still fly
             if (g.tim) t_first += __builtin_amdgcn_s_memtime() - w0;
         }
         for (int kt = 1; kt + 1 < nk; ++kt) {
@@ -379,30 +380,33 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         s_barrier_lgkm();
         if (has_next) { set_src(nm0, nn0, nbz); if (!RESK && !LNK) load_bias(nn0, nm0); }       // addresses first, loads after: no reload lands behind a DMA
         if (use_res) { if (interior) load_residual(yes{}, 0); else load_residual(no{}, 0); }
-        float er[LNK ? MT : 1];                     // LNK: rstd of THIS tile's rows for the epilogue, fetched under the last K-tile
-        if constexpr (LNK) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) er[t] = g.ln_stats[2 * (int64_t)min(m0 + wm * WR + t * 16 + l15, g.M - 1) + 1];
-        }
+
         multiply(yes{}, has_next, 0);                                              // last K-tile; the next tile's first one goes out
         const unsigned long long ts1 = g.tim ? __builtin_amdgcn_s_memtime() : 0;
         s_barrier_lgkm();                                                          // every wave is done with the stage just multiplied: it
                                                                                    // receives the next tile's SECOND K-tile inside pass 0
         // One 32-row MFMA tile per pass through this wave's private 4 KiB of staging.
-        if ((RESK || LNK) && has_next) load_bias(nn0, nm0);   // (with a residual / the row statistics the registers are tighter during the last K-tile: fetched here, still ahead of the stores)
+        if (RESK && has_next) load_bias(nn0, nm0);   // (with a residual the registers are tighter during the last K-tile: fetched here, still ahead of the stores)
         auto epilogue = [&](auto res_tag, auto int_tag) {
             constexpr bool RES = decltype(res_tag)::value, INT = decltype(int_tag)::value;
 #pragma unroll
             for (int h = 0; h < MI; ++h) {
+                float er_pass[2] = {1.f, 1.f};                            // LNK: rstd of this pass's rows (t = 2 h + tt): held by the lanes of 16-lane group h
+                if constexpr (LNK) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        er_pass[tt] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l15 + 16 * h) << 2, __builtin_bit_cast(int, ers[tt])));
+                }
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)                            // the two 16-row MFMA tiles of this 32-row pass
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         bf16x4 v;
+                        f32x4 xs = acc[2 * h + tt][j];
+                        if constexpr (LNK) xs = xs * er_pass[tt];            // one row, four columns: packed multiplies
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float x = acc[2 * h + tt][j][e];
-                            if constexpr (LNK) x *= er[2 * h + tt];
+                            float x = xs[e];
                             if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));   // x*sigmoid(1.702x); 1.702*log2(e)
                             else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                             v[e] = (bf16)x;
@@ -429,6 +433,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                     if (has_next) issue_ktile((cnt + 1) & 1, TK);
                 }
                 if (RES && h + 1 < MI) load_residual(int_tag, h + 1);     // requested before this pass's stores (vmcnt retires in order)
+                if (LNK && h == 1 && has_next) load_ln_frags(nn0, nm0);  // the next tile's fragments: into the registers the first two passes freed
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
@@ -468,6 +473,242 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 }
 
 // --------------------------------------------------------------------------------------------
+// Four-wave form of the main kernel: ONE wave per SIMD, 128 x 128 of the 256 x 256 tile per wave, 256 accumulator registers (the
+// register file gives a lone wave 512), v_mfma_f32_16x16x32_bf16.  Same tiles, LDS image, LDS-DMA addressing, continuous K-stream and
+// arithmetic per output element as gemm_persist_kernel (a row's bits do not depend on the kernel), but
+//   * the MFMA fragments are double-buffered in registers: the 16 ds_read_b128 of k-step s + 1 are in flight under the 64 MFMAs of
+//     k-step s, so the matrix pipe never waits for LDS and no second wave per SIMD is needed to cover the fetch (two waves per SIMD
+//     take turns at the pipe and idle 0.3-1.2 k cycles per K-tile at the barrier);
+//   * 16 fragment reads feed 64 MFMAs: 0.25 KiB of LDS traffic per MFMA instead of 0.375 — less energy per FLOP, which is what the
+//     power-managed clock pays back;
+//   * the multiply of a k-step lags its reads by one k-step ACROSS the K-tile barrier: the barrier wait is followed by reads whose
+//     latency the previous K-tile's last 64 MFMAs cover.
+// Experiment hook: SETOK_GEMM_W4=1 routes the launches without residual / folded LayerNorm here.
+// --------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(PArgs g) {
+    constexpr int TNB = 256, MT = 8, NT = 8;       // 16 x 16 MFMA tiles per wave: 8 along M x 8 along N
+    constexpr int NSTORE = 32;                     // 16-byte stores per lane per (interior) tile
+    constexpr int NL = 16;                         // LDS-DMA ops per lane per K-tile
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int nk = g.K / TK;
+    const int num_tiles = g.tilesM * g.tilesN;
+    const int G = gridDim.x;
+
+    auto tile_of = [&](int round, int& m0, int& n0) -> bool {
+        int L;
+        if ((G & 7) == 0) L = round * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        else L = round * G + blockIdx.x;
+        if (L >= num_tiles) return false;
+        constexpr int GM = 8;
+        const int per = GM * g.tilesN, group = L / per, first_m = group * GM;
+        const int gm = min(g.tilesM - first_m, GM), in = L - group * per;
+        m0 = (first_m + in % gm) * TM;
+        n0 = (in / gm) * TNB;
+        return true;
+    };
+
+    unsigned a_off[8], b_off[8];
+    const char* a_base; const char* b_base;
+    auto set_src = [&](int m0, int n0) {
+        a_base = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);
+        b_base = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.K);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
+            a_off[i] = (unsigned)min(row, g.M - 1 - m0) * (unsigned)(g.lda * 2) + kc * 16;
+            b_off[i] = (unsigned)min(row, g.N - 1 - n0) * (unsigned)(g.K * 2) + kc * 16;
+        }
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
+    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
+        unsigned keep;
+        const unsigned long long b64 = (unsigned long long)base;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
+    };
+    auto issue_ktile = [&](int stage, int k0) {
+        const unsigned sb = lds0 + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16(a_base + k0 * 2, a_off[i], sb + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16(b_base + k0 * 2, b_off[i], sb + BOFF + i * 4096);
+    };
+
+    struct Frag { bf16x8 w[NT], a[MT]; };
+    Frag F0, F1;
+    f32x4 acc[MT][NT];
+    auto rd = [&](Frag& F, int stage, int ks) {
+        const char* Ab = smem + stage * STAGE;
+        const char* Bb = Ab + BOFF;
+        const int sl = ((ks * 4 + g4) ^ swz(l15)) << 4;                // rows t * 16 + l15: the swizzle depends on l15 only
+#pragma unroll
+        for (int t = 0; t < NT; ++t) F.w[t] = *reinterpret_cast<const bf16x8*>(Bb + (wn * 128 + t * 16 + l15) * 128 + sl);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) F.a[t] = *reinterpret_cast<const bf16x8*>(Ab + (wm * 128 + t * 16 + l15) * 128 + sl);
+    };
+    auto mm = [&](const Frag& F) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.w[j], F.a[t], acc[t][j], 0, 0, 0);
+    };
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+    // 64 MFMAs with this lane's 8 pieces of one operand half of the next K-tile requested in between, one after every eighth MFMA
+    // (a vector-memory instruction holds its wave until the address unit takes it: back-to-back requests stall the MFMA stream)
+    auto mm_dma = [&](const Frag& F, auto half_tag, int stage, int k0) {
+        constexpr int half = decltype(half_tag)::value;
+        const unsigned sb = lds0 + stage * STAGE + half * BOFF;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.w[j], F.a[t], acc[t][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (half) dma16(b_base + k0 * 2, b_off[t], sb + t * 4096); else dma16(a_base + k0 * 2, a_off[t], sb + t * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
+
+    float nb[NT];                                   // the tile's bias: column j * 16 + l15 of the wave's 128, fetched a tile ahead
+    auto load_bias = [&](int n0_) {
+        const float* bp = g.bias ? g.bias + min(n0_ + wn * 128, g.N - 128) : g.zero_bias;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) nb[j] = g.bias ? bp[j * 16 + l15] : 0.f;
+    };
+
+    int m0, n0, round = 0;
+    if (!tile_of(0, m0, n0)) return;
+    set_src(m0, n0);
+    load_bias(n0);
+    issue_ktile(0, 0);
+    int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
+    int pend = 0;
+    wait_vm<0>();
+    s_barrier_lgkm();
+    rd(F0, 0, 0);
+    issue_ktile(1, TK);
+
+    for (;;) {
+        int nm0 = 0, nn0 = 0;
+        const bool has_next = tile_of(round + 1, nm0, nn0);
+
+        {   // accumulators start at the bias: the exact three-way bf16 split against a fragment of ones, as in the eight-wave kernel
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+            f32x4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 bw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bw[e] = (bf16)0.0f;
+                const float b = nb[j];
+                const float hi1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffff0000u);
+                const float r1 = b - hi1;
+                const float hi2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+                const float r2 = r1 - hi2;
+                const bool fin = __builtin_isfinite(b);
+                if (g4 == 0) {
+                    bw[0] = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, b) >> 16));
+                    bw[1] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r1) >> 16)) : (bf16)0.0f;
+                    bw[2] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16)) : (bf16)0.0f;
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, ones, z, 0, 0, 0);
+            }
+        }
+        // K-tile 0 of this tile: its k-step-0 fragments are in F0 already, K-tile 1 is in flight
+        {
+            const int st = cnt & 1;
+            fence(); rd(F1, st, 1); fence(); mm(F0); fence();
+            ++cnt;
+        }
+        for (int kt = 1; kt < nk; ++kt) {
+            if (kt == 1 && pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>();   // K-tile kt has landed (the previous tile's stores may fly)
+            s_barrier_lgkm();                                                       // ... for everyone; everyone has read the other stage
+            const bool last = kt + 1 == nk;
+            if (last && has_next) set_src(nm0, nn0);
+            // (the very last K-tile of the block requests K-tile 0 of its own tile again: nobody reads it, and the multiply stays branch-free)
+            const int k_next = last ? 0 : (kt + 1) * TK;
+            const int st = cnt & 1;
+            fence(); rd(F0, st, 0); fence();
+            mm_dma(F1, H0{}, st ^ 1, k_next);                                       // the previous K-tile's second k-step
+            fence(); rd(F1, st, 1); fence();
+            mm_dma(F0, H1{}, st ^ 1, k_next);
+            fence();
+            ++cnt;
+        }
+        // ---- tile boundary: F1 holds the last k-step.  The next tile's first K-tile is read and its second requested first.
+        const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N);
+        const int slot = lane & 15, lrow = lane >> 4;
+        const int col = n0 + wn * 128 + slot * 8;
+        const bool col_ok = col < g.N;
+        char* stg = smem + 2 * STAGE + wave * 8192;
+        if (has_next) {
+            load_bias(nn0);
+            wait_vm<0>();
+            s_barrier_lgkm();
+            const int st = cnt & 1;
+            fence(); rd(F0, st, 0); issue_ktile(st ^ 1, TK);
+        }
+        fence(); mm(F1); fence();
+
+        auto epilogue = [&](auto int_tag) {
+            constexpr bool INT = decltype(int_tag)::value;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        bf16x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[2 * h + tt][j][e];
+                            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
+                            else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
+                            v[e] = (bf16)x;
+                        }
+                        // 256-byte staging rows: row tt * 16 + l15, columns j * 16 + 4 * g4 .. + 3 = 16-byte slot j * 2 + (g4 >> 1), half g4 & 1
+                        const int srow = tt * 16 + l15;
+                        *reinterpret_cast<bf16x4*>(stg + srow * 256 + (((j * 2 + (g4 >> 1)) ^ (srow & 15)) << 4) + 8 * (g4 & 1)) = v;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // a wave re-reads only its own staging rows
+                bf16x8 ov[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + lrow;
+                    ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 256 + ((slot ^ (row & 15)) << 4));
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int grow = m0 + wm * 128 + h * 32 + it * 4 + lrow;
+                    if (INT || (grow < g.M && col_ok))
+                        *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = ov[it];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // staging rows read before the next pass overwrites them
+            }
+        };
+        if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        if (!has_next) break;
+        pend = interior ? NSTORE : -1;
+        m0 = nm0; n0 = nn0; ++round;
+    }
+    wait_vm<0>();
+}
+
+// --------------------------------------------------------------------------------------------
 // Tail kernel: the < 1-round remainder of M (p*256 rows; the ViT's 257 tokens per image leave one 256-row slab after every
 // exact number of rounds).  A handful of tiles cannot fill 256 CUs, so this launch is pure latency: with 256 x 64 tiles and three
 // stages it took 24 us (16 K-tiles at 1.5 us each) for 0.4 % of the GEMM's work — 7 % of its time.  Hence small tiles and a deep
@@ -478,7 +719,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 constexpr int TT = 64;                           // tail tile edge
 constexpr int TSTAGE = 2 * TT * TK * 2;          // A 8 KiB + W 8 KiB
 constexpr int TNS = 8;                           // stages
-constexpr int TAIL_LDS = TNS * TSTAGE + 1024;    // + bias row (+ LNK: column sums, row means, row rstds)
+constexpr int TAIL_LDS = TNS * TSTAGE + 2560;    // + bias row (+ LNK: row rstds, 64 column fragments, 64 row fragments)
 
 template <int ACT, bool LNK = false>
 __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
@@ -491,11 +732,13 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TT;
     float* sbias = reinterpret_cast<float*>(smem + TNS * TSTAGE);
     if (tid < 64) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
-    if constexpr (LNK) {                                    // sbias[64..127] column sums, [128..191] row means, [192..255] row rstds
+    if constexpr (LNK) {                                    // sbias[64..127] row rstds, then the 64 column fragments and the 64 row fragments (16 B each)
         if (tid < 64) {
-            sbias[64 + tid] = g.ln_colsum[min(n0 + tid, g.N - 1)];
-            const float2 st = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (int64_t)min(m0 + tid, g.M - 1));
-            sbias[128 + tid] = st.x; sbias[192 + tid] = st.y;
+            const float* st = g.ln_stats + 8 * (int64_t)min(m0 + tid, g.M - 1);
+            sbias[64 + tid] = st[4];
+            reinterpret_cast<f32x4*>(sbias + 128)[tid] = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)min(n0 + tid, g.N - 1));
+            const f32x4 rf = {st[0], st[0], st[1], st[1]};        // compact (-mean hi, lo), (1 / rstd hi, lo) -> the 8 k-slots
+            reinterpret_cast<f32x4*>(sbias + 384)[tid] = rf;
         }
     }
 
@@ -543,10 +786,10 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
                 for (int e = 0; e < 4; ++e) z[e] = 0.f;
                 bf16x8 cfr[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) cfr[j] = ln_col_frag(sbias[64 + wn * 32 + j * 16 + l15], sbias[wn * 32 + j * 16 + l15], g4);
+                for (int j = 0; j < 2; ++j) cfr[j] = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 128)[wn * 32 + j * 16 + l15], g4);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const bf16x8 rfr = ln_row_frag(sbias[128 + wm * 32 + t * 16 + l15], sbias[192 + wm * 32 + t * 16 + l15], g4);
+                    const bf16x8 rfr = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 384)[wm * 32 + t * 16 + l15], g4);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
                 }
@@ -588,7 +831,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[t][j][e];
-                if constexpr (LNK) x *= sbias[192 + wm * 32 + t * 16 + l15];
+                if constexpr (LNK) x *= sbias[64 + wm * 32 + t * 16 + l15];
                 if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
                 else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                 v[e] = (bf16)x;
@@ -650,6 +893,21 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
+    const char* e_w4 = getenv("SETOK_GEMM_W4");                                                               // experiment hook: the four-wave kernel
+    const bool use_w4 = e_w4 && e_w4[0] == '1';
+    if (use_w4 && !res && !g.ln_stats && g.N % 128 == 0) {
+        static SetokDeviceOnce once4;
+        if (!once4.run([] {
+                bool ok = hipFuncSetAttribute((const void*)gemm_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)gemm_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+                return ok && hipFuncSetAttribute((const void*)gemm_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess; }))
+            return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
+        if (act == SETOK_ACT_NONE) gemm_w4_kernel<0><<<grid, 256, MAIN_LDS, s>>>(g);
+        else if (act == SETOK_ACT_QUICK_GELU) gemm_w4_kernel<1><<<grid, 256, MAIN_LDS, s>>>(g);
+        else gemm_w4_kernel<2><<<grid, 256, MAIN_LDS, s>>>(g);
+        SETOK_CHECK_LAUNCH("setok_linear(persistent, 4 waves)");
+        return SETOK_OK;
+    }
     if (g.ln_stats) {
         if (act == SETOK_ACT_NONE) gemm_persist_kernel<0, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);
         else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);
@@ -732,7 +990,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
             lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1,
-            ln_stats ? ln_stats + 2 * (int64_t)m_off : nullptr, ln_colsum};
+            ln_stats ? ln_stats + 8 * (int64_t)m_off : nullptr, ln_colsum};
     return launch_tail(s, t, act);
 }
 

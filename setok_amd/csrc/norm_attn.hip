@@ -112,6 +112,17 @@ extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const flo
 //   row statistics {mean, rstd} — the first two passes of the kernels above, same summation order, no normalised copy written;
 //   the weight fold, once per weight load:  W' = bf16(gamma * W),  c = W' 1 (fp32, ascending k),  b' = b + W beta.
 // --------------------------------------------------------------------------------------------
+// stats row = 8 floats: [0] = (-mean hi, lo) and [1] = (1 / rstd hi, lo) as bf16 pairs — the compact form of the activation-side fragment
+// [mh, ml, mh, ml, sh, sl, sh, sl] (the GEMM duplicates the two words) — [2], [3] = 0, [4] = rstd, [5] = mean, [6], [7] = 0
+__device__ inline void write_row_stats(float* stats, int64_t row, float mean, float rstd) {
+    const f32x4 fr = __builtin_bit_cast(f32x4, ln_row_frag(mean, rstd));
+    f32x4* o = reinterpret_cast<f32x4*>(stats + 8 * row);
+    const f32x4 head = {fr[0], fr[2], 0.f, 0.f};
+    o[0] = head;
+    const f32x4 tail = {rstd, mean, 0.f, 0.f};
+    o[1] = tail;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int rows, int C, float eps) {
     constexpr int V = Elem<T>::VEC;
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x,
             for (int i = 0; i < V; ++i) { const float d = buf[i] - mean; q += d * d; }
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-        if (lane == 0) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
+        if (lane == 0) write_row_stats(stats, row, mean, rstd);
     }
 }
 
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void row_stats_1024_kernel(const bf16* __restr
 #pragma unroll
             for (int i = 0; i < V; ++i) { const float d = buf[k][i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-        if (lane == 0) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
+        if (lane == 0) write_row_stats(stats, row, mean, rstd);
     }
 }
 
@@ -181,7 +192,7 @@ extern "C" int setok_row_stats(void* stream, int dtype, const void* x, float* st
 // one wave per output row n of W (N, K)
 __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ bias, bf16* __restrict__ Wg, float* __restrict__ colsum,
-                                                      float* __restrict__ bias_folded, int N, int K) {
+                                                      float* __restrict__ bias_folded, float* __restrict__ colfrag, int N, int K) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -194,13 +205,17 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16* __restrict__ W
         bb += w * beta[k];
     }
     c = wave_sum(c); bb = wave_sum(bb);
-    if (lane == 0) { colsum[n] = c; bias_folded[n] = (bias ? bias[n] : 0.f) + bb; }
+    if (lane == 0) {
+        const float bf = (bias ? bias[n] : 0.f) + bb;
+        colsum[n] = c; bias_folded[n] = bf;
+        reinterpret_cast<f32x4*>(colfrag)[n] = __builtin_bit_cast(f32x4, ln_col_frag(c, bf));
+    }
 }
 
 extern "C" int setok_ln_fold(void* stream, const void* W, const float* gamma, const float* beta, const float* bias, void* w_gamma,
-                             float* w_colsum, float* bias_folded, int N, int K) {
-    SETOK_CHECK_ARG(W && gamma && beta && w_gamma && w_colsum && bias_folded && N > 0 && K > 0, "setok_ln_fold: bad argument");
-    ln_fold_kernel<<<cdiv(N, 4), 256, 0, (hipStream_t)stream>>>((const bf16*)W, gamma, beta, bias, (bf16*)w_gamma, w_colsum, bias_folded, N, K);
+                             float* w_colsum, float* bias_folded, float* col_frag, int N, int K) {
+    SETOK_CHECK_ARG(W && gamma && beta && w_gamma && w_colsum && bias_folded && col_frag && N > 0 && K > 0, "setok_ln_fold: bad argument");
+    ln_fold_kernel<<<cdiv(N, 4), 256, 0, (hipStream_t)stream>>>((const bf16*)W, gamma, beta, bias, (bf16*)w_gamma, w_colsum, bias_folded, col_frag, N, K);
     SETOK_CHECK_LAUNCH("setok_ln_fold");
     return SETOK_OK;
 }

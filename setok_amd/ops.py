@@ -56,21 +56,33 @@ def k_align(dt: torch.dtype) -> int:
     return 64 if dt == torch.bfloat16 else 16
 
 
-# ---- optional launch profiler (bench.py): HIP events on the launch stream around every GEMM -------------
-_PROFILE = None
+# ---- optional launch profiler (bench.py): HIP events recorded INSIDE the library around every GEMM / clustering call ---------------------
+_ACT_NAMES = ("plain", "quick_gelu", "gelu_erf")
 
 
 def profile_start() -> None:
-    global _PROFILE
-    _PROFILE = []
+    _lib.call("setok_profile_start")
 
 
 def profile_stop():
-    """Synchronise and return [{kernel, flops, ms}] for every launch recorded since profile_start()."""
-    global _PROFILE
-    rec, _PROFILE = _PROFILE or [], None
-    torch.cuda.synchronize()
-    return [dict(kernel=k, flops=f, ms=e0.elapsed_time(e1), bytes=b) for k, f, e0, e1, b in rec]
+    """Synchronise and return [{kernel, flops, ms, bytes}] for every launch the library recorded since profile_start()."""
+    import numpy as np
+    cap = 1 << 16
+    kind, cls = np.empty(cap, np.int32), np.empty(cap, np.int32)
+    work, nbytes, ms = np.empty(cap, np.float64), np.empty(cap, np.float64), np.empty(cap, np.float32)
+    n = _lib.load().setok_profile_stop(kind.ctypes.data, cls.ctypes.data, work.ctypes.data, nbytes.ctypes.data, ms.ctypes.data, cap)
+    if n < 0:
+        raise _lib.SetokHipError("setok_profile_stop failed")
+    out = []
+    for i in range(n):
+        if kind[i] == 2:
+            name, w = "cluster_dpc_knn", float(nbytes[i])            # the clustering record's headline quantity is algorithmic BYTES
+        else:
+            c = int(cls[i])
+            name = ("gemm_bf16:" if kind[i] == 0 else "gemm_f32:") + _ACT_NAMES[c & 3] + ("+residual" if c & 4 else "") + ("+layernorm" if c & 8 else "")
+            w = float(work[i])
+        out.append(dict(kernel=name, flops=w, ms=float(ms[i]), bytes=float(nbytes[i])))
+    return out
 
 
 def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
@@ -85,17 +97,8 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Option
     assert out.shape == (M, N) and out.dtype == od
     if residual is not None:
         assert residual.shape == (M, N) and residual.dtype == od
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("setok_linear", _stream(), _code(a.dtype), _code(od), _p(a), K, _p(w), _p(_f32(bias)), _p(residual),
               _p(out), N, M, N, K, act, 1, 0, 0, 0)
-    if _PROFILE is not None:
-        e1.record()
-        # class = activation + residual (one kernel instantiation each); algorithmic bytes = A, W (+ residual) read once, C written once
-        alg = (M * K + N * K) * a.element_size() + M * N * out.element_size() * (2 if residual is not None else 1)
-        _PROFILE.append((("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32") + ":" + ("plain", "quick_gelu", "gelu_erf")[act]
-                         + ("+residual" if residual is not None else ""), 2.0 * M * N * K, e0, e1, float(alg)))
     return out
 
 
@@ -109,42 +112,37 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, out: Op
 
 # ---- LayerNorm folded into the consuming Linear (bf16 throughput mode; include/setok_hip.h explains the algebra) -------------------------
 def row_stats(x: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Tensor:
-    """(rows, 2) fp32: {mean, 1 / sqrt(var + eps)} of every row of x, the statistics setok_layernorm computes, without writing a normalised copy."""
+    """(rows, 8) fp32 words per row: [0:2] the compact MFMA fragment of (-mean, 1 / rstd) (bf16 pairs), [4] rstd = 1 / sqrt(var + eps), [5] mean — the
+    statistics setok_layernorm computes, without writing a normalised copy."""
     rows, Cc = x.shape
     if out is None:
-        out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
-    assert out.shape == (rows, 2) and out.dtype == torch.float32
+        out = torch.empty((rows, 8), dtype=torch.float32, device=x.device)
+    assert out.shape == (rows, 8) and out.dtype == torch.float32
     _lib.call("setok_row_stats", _stream(), _code(x.dtype), _p(x), _p(out), rows, Cc, eps)
     return out
 
 
-def ln_fold(w: Tensor, gamma: Tensor, beta: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
-    """Once per weight load: (W' = bf16(gamma * W), c = W' 1, b' = b + W beta) for linear_ln."""
+def ln_fold(w: Tensor, gamma: Tensor, beta: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Once per weight load: (W' = bf16(gamma * W), c = W' 1, b' = b + W beta, the (N, 4)-word MFMA fragments of (c, b')) for linear_ln."""
     assert w.dtype == torch.bfloat16 and w.dim() == 2
     N, K = w.shape
     wg = torch.empty_like(w)
     cs = torch.empty((N,), dtype=torch.float32, device=w.device)
     bf = torch.empty((N,), dtype=torch.float32, device=w.device)
-    _lib.call("setok_ln_fold", _stream(), _p(w.contiguous()), _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(bias)), _p(wg), _p(cs), _p(bf), N, K)
-    return wg, cs, bf
+    fr = torch.empty((N, 4), dtype=torch.float32, device=w.device)
+    _lib.call("setok_ln_fold", _stream(), _p(w.contiguous()), _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(bias)), _p(wg), _p(cs), _p(bf), _p(fr), N, K)
+    return wg, cs, bf, fr
 
 
-def linear_ln(a: Tensor, folded: Tuple[Tensor, Tensor, Tensor], stats: Tensor, act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
-    """out = act(LayerNorm(a) @ W.T + b) from the raw rows `a`, their statistics and the folded weight triple of ln_fold."""
-    wg, cs, bf = folded
+def linear_ln(a: Tensor, folded: Tuple[Tensor, Tensor, Tensor, Tensor], stats: Tensor, act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """out = act(LayerNorm(a) @ W.T + b) from the raw rows `a`, their statistics and the folded weights of ln_fold."""
+    wg, _, _, fr = folded
     M, K = a.shape
     N = wg.shape[0]
-    assert a.dtype == torch.bfloat16 and wg.shape[1] == K and stats.shape == (M, 2)
+    assert a.dtype == torch.bfloat16 and wg.shape[1] == K and stats.shape == (M, 8)
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.call("setok_linear_ln", _stream(), _p(a), K, _p(wg), _p(cs), _p(bf), _p(stats), _p(out), N, M, N, K, act)
-    if _PROFILE is not None:
-        e1.record()
-        alg = (M * K + N * K) * 2 + M * N * 2 + M * 8
-        _PROFILE.append(("gemm_bf16:" + ("plain", "quick_gelu", "gelu_erf")[act] + "+layernorm", 2.0 * M * N * K, e0, e1, float(alg)))
+    _lib.call("setok_linear_ln", _stream(), _p(a), K, _p(wg), _p(fr), _p(stats), _p(out), N, M, N, K, act)
     return out
 
 
@@ -226,16 +224,9 @@ def cluster_dpc_knn(x: Tensor, B: int, N: int, k: int, threshold: float, min_clu
     if token_mask is not None:
         token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
         assert token_mask.numel() == B * N
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("setok_cluster_dpc_knn", _stream(), _code(x.dtype), _p(x), B, N, Cc, int(k), float(threshold),
               int(min_cluster_num), _p(noise), _p(token_mask), _p(idx), _p(score), _p(index_down), _p(counts),
               _p(dist_ws), _p(vec_ws))
-    if _PROFILE is not None:
-        e1.record()
-        # algorithmic bytes: read x once, write idx_cluster (int64), score (fp32), index_down (int64, <= N)
-        _PROFILE.append(("cluster_dpc_knn", float(B) * (N * Cc * x.element_size() + N * 8 + N * 4 + N * 8), e0, e1, 0.0))
     return idx, score, index_down, counts
 
 

@@ -16,6 +16,7 @@ ragged return type.
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Dict, List, Optional, Sequence, Union
 
 import numpy as np
@@ -63,6 +64,9 @@ class Block(PackCacheMixin, nn.Module):
         if drop_path > 0.0:
             raise ValueError("drop_path > 0 is a training-time regulariser; the HIP path is eval-only")
         self.dim, self.num_heads = dim, num_heads
+        # kept for the training step's check: the forward here is the eval-mode arithmetic (nn.Dropout is the identity in eval mode);
+        # the reference TRAINS with Attention.proj_drop and both Mlp.drop active at this rate (module.py:36,44,59,72)
+        self.proj_drop_p, self.attn_drop_p = float(proj_drop or 0.0), float(attn_drop or 0.0)
         self.norm1 = norm_layer(dim)
         self.drop_path = nn.Identity()
         self.norm2 = norm_layer(dim)
@@ -365,10 +369,36 @@ class SetokTokenizer(nn.Module):
         if x.dim() == 3:
             x = x.unsqueeze(0)
         B = x.shape[0]
-        hidden = self.image_feature_encoder.hidden_rows(x)                         # tokenizer.py:161
-        if hidden.dtype != self.dtype:
-            hidden = hidden.to(self.dtype)
-        return self.encode_features(hidden, B, k, threshold, token_mask, noise)
+        if os.environ.get("SETOK_HOST_PATH", "0") == "1":                          # the same path op by op from Python (A/B runs, tests of the two forms)
+            hidden = self.image_feature_encoder.hidden_rows(x)                     # tokenizer.py:161
+            if hidden.dtype != self.dtype:
+                hidden = hidden.to(self.dtype)
+            return self.encode_features(hidden, B, k, threshold, token_mask, noise)
+        tower = self.image_feature_encoder
+        if not tower.is_loaded:
+            raise RuntimeError("vision tower not loaded: call load_model() first")
+        cfg = tower.config
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != cfg.image_size or x.shape[3] != cfg.image_size:
+            raise ValueError(f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
+        if tower.select_feature not in ("patch", "cls_patch"):
+            raise ValueError(f"Unexpected select feature: {tower.select_feature}")
+        tokens, counts, idx, score, _ = self._context().encode(x, k, threshold, noise, token_mask)
+        return RaggedTokens(tokens, counts), idx, score.reshape(B, 1, -1)
+
+    def _context(self):
+        """The library-side context holding this module's weights (rebuilt when they, the dtype or the device change)."""
+        from .context import EncodeContext
+        if self.__dict__.get("_ctx_params") is None:
+            self.__dict__["_ctx_params"] = list(self.parameters())
+        key = (self.dtype, str(self.device), self.image_feature_encoder.select_layer, self.image_feature_encoder.select_feature,
+               self.min_cluster_num, float(self.threshold), os.environ.get("SETOK_LN_FOLD", "1"), sum(p._version for p in self._ctx_params),
+               tuple(p.data_ptr() for p in self._ctx_params[:4]))
+        hit = self.__dict__.get("_ctx")
+        if hit is None or hit[0] != key:
+            self.__dict__["_ctx"] = None                                          # free the old copy of the weights first
+            hit = (key, EncodeContext(self, fold_layernorm=os.environ.get("SETOK_LN_FOLD", "1") != "0"))
+            self.__dict__["_ctx"] = hit
+        return hit[1]
 
     @torch.no_grad()
     def encode_batch(self, images: torch.Tensor, **kw):

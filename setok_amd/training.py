@@ -164,7 +164,21 @@ class HeadTrainer:
     """
 
     def __init__(self, tok: SetokTokenizer, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, process_group=None, bucket_bytes: int = 64 << 20):
+                 weight_decay: float = 0.0, process_group=None, bucket_bytes: int = 64 << 20, dropout: str = "warn"):
+        """`dropout`: the reference trains the head with Attention.proj_drop and both Mlp.drop at `proj_drop` (0.2 by default,
+        tokenizer.py:23, module.py:36,44,59,72).  This training step runs the head's EVAL-mode arithmetic — no dropout masks in the forward
+        or backward pass — i.e. it optimises the unregularised objective.  "warn" (default) says so once when the module was built with a
+        non-zero rate, "error" refuses, "eval" accepts silently (the caller knows: benchmarks, parity tests against eval-mode gradients)."""
+        rates = {n: (getattr(b, "proj_drop_p", 0.0), getattr(b, "attn_drop_p", 0.0)) for n, b in (("inner_encoder", tok.inner_encoder), ("inter_encoder", tok.inter_encoder))}
+        if dropout not in ("warn", "error", "eval"):
+            raise ValueError(f"dropout must be 'warn', 'error' or 'eval', got {dropout!r}")
+        if any(p > 0.0 or a > 0.0 for p, a in rates.values()) and dropout != "eval":
+            msg = (f"HeadTrainer runs the head without dropout (eval-mode arithmetic), but the module was built with (proj_drop, attn_drop) = {rates}: "
+                   "the reference trains with these masks active (module.py:29-73); pass dropout='eval' to accept the unregularised objective")
+            if dropout == "error":
+                raise NotImplementedError(msg)
+            import warnings
+            warnings.warn(msg, stacklevel=2)
         self.tok = tok
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.group = process_group

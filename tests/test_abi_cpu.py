@@ -23,7 +23,7 @@ def lib():
 def _declared():
     text = open(os.path.join(ROOT, "include", "setok_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    decls = re.findall(r"\b(?:int|const char\*)\s+(setok_\w+)\s*\(([^;]*)\)\s*;", text, flags=re.S)
+    decls = re.findall(r"\b(?:int64_t|int|void|const char\*)\s+(setok_\w+)\s*\(([^;]*)\)\s*;", text, flags=re.S)
     return {name: [a for a in args.split(",") if a.strip() and a.strip() != "void"] for name, args in decls}
 
 
@@ -44,7 +44,7 @@ def test_ctypes_table_matches_header(lib):
 
 def test_abi_version_and_error_plumbing(lib):
     l = lib.load()
-    assert l.setok_abi_version() == 2
+    assert l.setok_abi_version() == 3
     # argument validation happens on the host before any launch: usable without a GPU
     rc = l.setok_linear(None, 0, 0, None, 0, None, None, None, None, 0, 1, 1, 16, 0, 1, 0, 0, 0)
     assert rc == -1 and b"null operand" in l.setok_last_error()

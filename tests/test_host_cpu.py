@@ -157,3 +157,21 @@ def test_config_get_reads_dicts_and_attribute_objects():
     assert config_get(dict(tokenizer_padding_side="left"), "tokenizer_padding_side", "right") == "left"
     assert config_get(type("C", (), dict(tokenizer_model_max_length=7))(), "tokenizer_model_max_length") == 7
     assert config_get(None, "x", 3) == 3 and config_get({}, "x", 4) == 4
+
+
+def test_head_trainer_says_that_it_trains_without_dropout():
+    """The reference trains the head with proj_drop = 0.2 active (module.py:29-73); the hand-written training step runs eval-mode arithmetic
+    and must say so instead of silently optimising another objective."""
+    from setok_amd.training import HeadTrainer
+    tok = _small_tok(0)                                            # built with the reference's default proj_drop = 0.2
+    assert tok.inner_encoder.proj_drop_p == 0.2 and tok.inter_encoder.attn_drop_p == 0.0
+    with pytest.warns(UserWarning, match="without dropout"):
+        HeadTrainer(tok)
+    with pytest.raises(NotImplementedError):
+        HeadTrainer(tok, dropout="error")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        HeadTrainer(tok, dropout="eval")                           # accepted explicitly: silent
+    with pytest.raises(ValueError):
+        HeadTrainer(tok, dropout="maybe")

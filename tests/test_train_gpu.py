@@ -181,7 +181,7 @@ def test_trainer_step_matches_torch_adamw(golden_dir):
     shift-invariant — so its rounding-noise sign, which is all a first Adam step sees, is not comparable across implementations)."""
     sd, hidden, ups, ref, thr, _ = _grad_case(golden_dir)
     tok = _small_tok(sd)
-    tr = HeadTrainer(tok, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    tr = HeadTrainer(tok, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, dropout="eval")
     before = {n: p.detach().clone() for n, p in tr.params.items()}
     _, ctx = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr)
     tr.backward(ctx, torch.cat(ups, 0).to(DEV))
@@ -206,7 +206,7 @@ def test_training_step_bf16_runs_and_reduces_loss():
     vc = dict(hidden_size=C, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, image_size=112, patch_size=14)
     tok = SetokTokenizer(vision_tower=vc, mm_vision_select_layer=-2, hidden_dim=C, token_feat_dim=128, min_cluster_num=8,
                          threshold=0.5, nheads=2, dim_feedforward=512).to(device=DEV, dtype=torch.bfloat16).eval()
-    tr = HeadTrainer(tok, lr=2e-3)
+    tr = HeadTrainer(tok, lr=2e-3, dropout="eval")
     g = torch.Generator().manual_seed(0)
     hidden = torch.randn(B * (N + 1), C, generator=g).to(device=DEV, dtype=torch.bfloat16)
     losses = []
@@ -257,7 +257,7 @@ def test_training_checkpoint_resume_is_bit_exact(tmp_path):
         torch.manual_seed(seed)
         t = SetokTokenizer(vision_tower=vc, mm_vision_select_layer=-2, hidden_dim=C, token_feat_dim=128, min_cluster_num=8,
                            threshold=0.5, nheads=2, dim_feedforward=512).to(device=DEV, dtype=torch.bfloat16).eval()
-        return t, HeadTrainer(t, lr=2e-3, weight_decay=0.01)
+        return t, HeadTrainer(t, lr=2e-3, weight_decay=0.01, dropout="eval")
 
     g = torch.Generator().manual_seed(0)
     hidden = torch.randn(B * (N + 1), C, generator=g).to(device=DEV, dtype=torch.bfloat16)

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from setok_amd import ops
 B, T, H = 256, 257, 16
+if len(sys.argv) > 4:                                        # python tools/bench_attn.py 64 257 4096 1 : one head per "image" (rows of 3 * 64 elements)
+    H = int(sys.argv[4])
 if len(sys.argv) > 2:                                        # python tools/bench_attn.py 64 577 128 : the 336^2 tower (cfg4)
     T, B = int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 128
 Dh = int(sys.argv[1]) if len(sys.argv) > 1 else 64          # 64: the ViT-L tower; 48: the reconstruction decoder's ViT blocks

@@ -19,6 +19,7 @@ for name, N, act in (("qkv", 3072, 0), ("fc1+quick_gelu", 4096, 1)):
     variants = {"plain": lambda: ops.linear(x, w, b, act=act, out=out), "ln-fold": lambda: ops.linear_ln(x, folded, stats, act=act, out=out)}
     for rnd in range(2):
         for vn, fn in variants.items():
+            print(f"--- {name} {vn}", file=sys.stderr, flush=True)
             fn(); torch.cuda.synchronize()
             t0 = time.perf_counter(); n = 0
             while time.perf_counter() - t0 < secs:

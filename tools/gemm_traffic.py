@@ -45,13 +45,13 @@ def need(d, sub, what):
 
 
 def gemm_class(name):
-    m = re.search(r"gemm_persist_kernel<\s*(\d+)\s*,\s*(\w+)\s*(?:,\s*(\w+)\s*)?>", name)
+    m = re.search(r"gemm_persist_kernel<\s*(\d+)\s*,\s*(\w+)\s*(?:,\s*(\w+)\s*)?(?:,\s*(\w+)\s*)?>", name)
     if not m:
         return name
-    act, f32b, resk = m.group(1), m.group(2), m.group(3) or "false"
+    act, f32b, resk, lnk = m.group(1), m.group(2), m.group(3) or "false", m.group(4) or "false"
     if f32b in ("true", "1"):
         return "fp32_batched"
-    return ACT.get(act, act) + ("+residual" if resk in ("true", "1") else "")
+    return ACT.get(act, act) + ("+residual" if resk in ("true", "1") else "") + ("+layernorm" if lnk in ("true", "1") else "")
 
 
 def main():
@@ -99,7 +99,7 @@ def main():
     cl_total = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in cl.values()) / max(calls or 1, 1)
 
     print(json.dumps({
-        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline",
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --timed-only",
         "fetch_correction": corr,
         "calibration": f"{cal[0]}, same run: FETCH_SIZE {cal[1] / 1e6:.1f} MB vs WRITE_SIZE {cal[2] / 1e6:.1f} MB for a stream that reads and writes the "
                        f"same number of bytes (16 B per lane) -> x{corr:g}",

@@ -6,10 +6,10 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pk /tmp/pf /tmp/pw
-( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ) > $out/bench_under_rocprof.log 2>&1
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python bench.py --steps 5 --warmup 2 --timed-only ) > $out/bench_under_rocprof.log 2>&1
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/pk -name "*.db" | head -1) > $out/bench_kernel_stats.csv
-( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline ) > $out/pmc_fetch.log 2>&1
-( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline ) > $out/pmc_write.log 2>&1
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o f -- python bench.py --steps 2 --warmup 1 --timed-only ) > $out/pmc_fetch.log 2>&1
+( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o w -- python bench.py --steps 2 --warmup 1 --timed-only ) > $out/pmc_write.log 2>&1
 F=$(find /tmp/pf -name "*.db" | head -1); W=$(find /tmp/pw -name "*.db" | head -1)
 python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $F > $out/bench_pmc_FETCH_SIZE.txt
 python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $W > $out/bench_pmc_WRITE_SIZE.txt

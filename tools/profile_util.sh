@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for m in MfmaUtil LdsUtil LdsBankConflict; do
   rm -rf /tmp/pu_$m
-  ( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --pmc $m -d /tmp/pu_$m -o u -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline ) > $out/pmc_$m.log 2>&1
+  ( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --pmc $m -d /tmp/pu_$m -o u -- python bench.py --steps 2 --warmup 1 --timed-only ) > $out/pmc_$m.log 2>&1
   db=$(find /tmp/pu_$m -name "*.db" | head -1)
   if [ -n "$db" ]; then python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $db > $out/bench_pmc_$m.txt; grep -A3 "gemm_persist_kernel<0>\|gemm_persist_kernel<1>\|attn_vit" $out/bench_pmc_$m.txt | head -16; else tail -3 $out/pmc_$m.log; fi
 done
