@@ -473,242 +473,6 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Four-wave form of the main kernel: ONE wave per SIMD, 128 x 128 of the 256 x 256 tile per wave, 256 accumulator registers (the
-// register file gives a lone wave 512), v_mfma_f32_16x16x32_bf16.  Same tiles, LDS image, LDS-DMA addressing, continuous K-stream and
-// arithmetic per output element as gemm_persist_kernel (a row's bits do not depend on the kernel), but
-//   * the MFMA fragments are double-buffered in registers: the 16 ds_read_b128 of k-step s + 1 are in flight under the 64 MFMAs of
-//     k-step s, so the matrix pipe never waits for LDS and no second wave per SIMD is needed to cover the fetch (two waves per SIMD
-//     take turns at the pipe and idle 0.3-1.2 k cycles per K-tile at the barrier);
-//   * 16 fragment reads feed 64 MFMAs: 0.25 KiB of LDS traffic per MFMA instead of 0.375 — less energy per FLOP, which is what the
-//     power-managed clock pays back;
-//   * the multiply of a k-step lags its reads by one k-step ACROSS the K-tile barrier: the barrier wait is followed by reads whose
-//     latency the previous K-tile's last 64 MFMAs cover.
-// Experiment hook: SETOK_GEMM_W4=1 routes the launches without residual / folded LayerNorm here.
-// --------------------------------------------------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(256) void gemm_w4_kernel(PArgs g) {
-    constexpr int TNB = 256, MT = 8, NT = 8;       // 16 x 16 MFMA tiles per wave: 8 along M x 8 along N
-    constexpr int NSTORE = 32;                     // 16-byte stores per lane per (interior) tile
-    constexpr int NL = 16;                         // LDS-DMA ops per lane per K-tile
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int nk = g.K / TK;
-    const int num_tiles = g.tilesM * g.tilesN;
-    const int G = gridDim.x;
-
-    auto tile_of = [&](int round, int& m0, int& n0) -> bool {
-        int L;
-        if ((G & 7) == 0) L = round * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-        else L = round * G + blockIdx.x;
-        if (L >= num_tiles) return false;
-        constexpr int GM = 8;
-        const int per = GM * g.tilesN, group = L / per, first_m = group * GM;
-        const int gm = min(g.tilesM - first_m, GM), in = L - group * per;
-        m0 = (first_m + in % gm) * TM;
-        n0 = (in / gm) * TNB;
-        return true;
-    };
-
-    unsigned a_off[8], b_off[8];
-    const char* a_base; const char* b_base;
-    auto set_src = [&](int m0, int n0) {
-        a_base = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);
-        b_base = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.K);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
-            a_off[i] = (unsigned)min(row, g.M - 1 - m0) * (unsigned)(g.lda * 2) + kc * 16;
-            b_off[i] = (unsigned)min(row, g.N - 1 - n0) * (unsigned)(g.K * 2) + kc * 16;
-        }
-    };
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
-    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
-        unsigned keep;
-        const unsigned long long b64 = (unsigned long long)base;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
-        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
-        const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
-    };
-    auto issue_ktile = [&](int stage, int k0) {
-        const unsigned sb = lds0 + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dma16(a_base + k0 * 2, a_off[i], sb + i * 4096);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dma16(b_base + k0 * 2, b_off[i], sb + BOFF + i * 4096);
-    };
-
-    struct Frag { bf16x8 w[NT], a[MT]; };
-    Frag F0, F1;
-    f32x4 acc[MT][NT];
-    auto rd = [&](Frag& F, int stage, int ks) {
-        const char* Ab = smem + stage * STAGE;
-        const char* Bb = Ab + BOFF;
-        const int sl = ((ks * 4 + g4) ^ swz(l15)) << 4;                // rows t * 16 + l15: the swizzle depends on l15 only
-#pragma unroll
-        for (int t = 0; t < NT; ++t) F.w[t] = *reinterpret_cast<const bf16x8*>(Bb + (wn * 128 + t * 16 + l15) * 128 + sl);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) F.a[t] = *reinterpret_cast<const bf16x8*>(Ab + (wm * 128 + t * 16 + l15) * 128 + sl);
-    };
-    auto mm = [&](const Frag& F) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.w[j], F.a[t], acc[t][j], 0, 0, 0);
-    };
-    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-    // 64 MFMAs with this lane's 8 pieces of one operand half of the next K-tile requested in between, one after every eighth MFMA
-    // (a vector-memory instruction holds its wave until the address unit takes it: back-to-back requests stall the MFMA stream)
-    auto mm_dma = [&](const Frag& F, auto half_tag, int stage, int k0) {
-        constexpr int half = decltype(half_tag)::value;
-        const unsigned sb = lds0 + stage * STAGE + half * BOFF;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.w[j], F.a[t], acc[t][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (half) dma16(b_base + k0 * 2, b_off[t], sb + t * 4096); else dma16(a_base + k0 * 2, a_off[t], sb + t * 4096);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
-
-    float nb[NT];                                   // the tile's bias: column j * 16 + l15 of the wave's 128, fetched a tile ahead
-    auto load_bias = [&](int n0_) {
-        const float* bp = g.bias ? g.bias + min(n0_ + wn * 128, g.N - 128) : g.zero_bias;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) nb[j] = g.bias ? bp[j * 16 + l15] : 0.f;
-    };
-
-    int m0, n0, round = 0;
-    if (!tile_of(0, m0, n0)) return;
-    set_src(m0, n0);
-    load_bias(n0);
-    issue_ktile(0, 0);
-    int cnt = 0;                                   // position in the K-tile stream (stage = cnt & 1)
-    int pend = 0;
-    wait_vm<0>();
-    s_barrier_lgkm();
-    rd(F0, 0, 0);
-    issue_ktile(1, TK);
-
-    for (;;) {
-        int nm0 = 0, nn0 = 0;
-        const bool has_next = tile_of(round + 1, nm0, nn0);
-
-        {   // accumulators start at the bias: the exact three-way bf16 split against a fragment of ones, as in the eight-wave kernel
-            bf16x8 ones;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-            f32x4 z;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                bf16x8 bw;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bw[e] = (bf16)0.0f;
-                const float b = nb[j];
-                const float hi1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffff0000u);
-                const float r1 = b - hi1;
-                const float hi2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
-                const float r2 = r1 - hi2;
-                const bool fin = __builtin_isfinite(b);
-                if (g4 == 0) {
-                    bw[0] = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, b) >> 16));
-                    bw[1] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r1) >> 16)) : (bf16)0.0f;
-                    bw[2] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16)) : (bf16)0.0f;
-                }
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, ones, z, 0, 0, 0);
-            }
-        }
-        // K-tile 0 of this tile: its k-step-0 fragments are in F0 already, K-tile 1 is in flight
-        {
-            const int st = cnt & 1;
-            fence(); rd(F1, st, 1); fence(); mm(F0); fence();
-            ++cnt;
-        }
-        for (int kt = 1; kt < nk; ++kt) {
-            if (kt == 1 && pend == NSTORE) wait_vm<NSTORE>(); else wait_vm<0>();   // K-tile kt has landed (the previous tile's stores may fly)
-            s_barrier_lgkm();                                                       // ... for everyone; everyone has read the other stage
-            const bool last = kt + 1 == nk;
-            if (last && has_next) set_src(nm0, nn0);
-            // (the very last K-tile of the block requests K-tile 0 of its own tile again: nobody reads it, and the multiply stays branch-free)
-            const int k_next = last ? 0 : (kt + 1) * TK;
-            const int st = cnt & 1;
-            fence(); rd(F0, st, 0); fence();
-            mm_dma(F1, H0{}, st ^ 1, k_next);                                       // the previous K-tile's second k-step
-            fence(); rd(F1, st, 1); fence();
-            mm_dma(F0, H1{}, st ^ 1, k_next);
-            fence();
-            ++cnt;
-        }
-        // ---- tile boundary: F1 holds the last k-step.  The next tile's first K-tile is read and its second requested first.
-        const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N);
-        const int slot = lane & 15, lrow = lane >> 4;
-        const int col = n0 + wn * 128 + slot * 8;
-        const bool col_ok = col < g.N;
-        char* stg = smem + 2 * STAGE + wave * 8192;
-        if (has_next) {
-            load_bias(nn0);
-            wait_vm<0>();
-            s_barrier_lgkm();
-            const int st = cnt & 1;
-            fence(); rd(F0, st, 0); issue_ktile(st ^ 1, TK);
-        }
-        fence(); mm(F1); fence();
-
-        auto epilogue = [&](auto int_tag) {
-            constexpr bool INT = decltype(int_tag)::value;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        bf16x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = acc[2 * h + tt][j][e];
-                            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
-                            else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
-                            v[e] = (bf16)x;
-                        }
-                        // 256-byte staging rows: row tt * 16 + l15, columns j * 16 + 4 * g4 .. + 3 = 16-byte slot j * 2 + (g4 >> 1), half g4 & 1
-                        const int srow = tt * 16 + l15;
-                        *reinterpret_cast<bf16x4*>(stg + srow * 256 + (((j * 2 + (g4 >> 1)) ^ (srow & 15)) << 4) + 8 * (g4 & 1)) = v;
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // a wave re-reads only its own staging rows
-                bf16x8 ov[8];
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int row = it * 4 + lrow;
-                    ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 256 + ((slot ^ (row & 15)) << 4));
-                }
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int grow = m0 + wm * 128 + h * 32 + it * 4 + lrow;
-                    if (INT || (grow < g.M && col_ok))
-                        *reinterpret_cast<bf16x8*>(g.C + (int64_t)grow * g.ldc + col) = ov[it];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // staging rows read before the next pass overwrites them
-            }
-        };
-        if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
-        if (!has_next) break;
-        pend = interior ? NSTORE : -1;
-        m0 = nm0; n0 = nn0; ++round;
-    }
-    wait_vm<0>();
-}
-
-// --------------------------------------------------------------------------------------------
 // Tail kernel: the < 1-round remainder of M (p*256 rows; the ViT's 257 tokens per image leave one 256-row slab after every
 // exact number of rounds).  A handful of tiles cannot fill 256 CUs, so this launch is pure latency: with 256 x 64 tiles and three
 // stages it took 24 us (16 K-tiles at 1.5 us each) for 0.4 % of the GEMM's work — 7 % of its time.  Hence small tiles and a deep
@@ -893,21 +657,6 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu) {
     const int tiles = g.tilesM * g.tilesN;
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
-    const char* e_w4 = getenv("SETOK_GEMM_W4");                                                               // experiment hook: the four-wave kernel
-    const bool use_w4 = e_w4 && e_w4[0] == '1';
-    if (use_w4 && !res && !g.ln_stats && g.N % 128 == 0) {
-        static SetokDeviceOnce once4;
-        if (!once4.run([] {
-                bool ok = hipFuncSetAttribute((const void*)gemm_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-                ok = ok && hipFuncSetAttribute((const void*)gemm_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
-                return ok && hipFuncSetAttribute((const void*)gemm_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess; }))
-            return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
-        if (act == SETOK_ACT_NONE) gemm_w4_kernel<0><<<grid, 256, MAIN_LDS, s>>>(g);
-        else if (act == SETOK_ACT_QUICK_GELU) gemm_w4_kernel<1><<<grid, 256, MAIN_LDS, s>>>(g);
-        else gemm_w4_kernel<2><<<grid, 256, MAIN_LDS, s>>>(g);
-        SETOK_CHECK_LAUNCH("setok_linear(persistent, 4 waves)");
-        return SETOK_OK;
-    }
     if (g.ln_stats) {
         if (act == SETOK_ACT_NONE) gemm_persist_kernel<0, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);
         else if (act == SETOK_ACT_QUICK_GELU) gemm_persist_kernel<1, false, false, true><<<grid, 512, MAIN_LDS, s>>>(g);

@@ -203,12 +203,14 @@ class HeadTrainer:
     def _allreduce_module(self, mod: str, g: Dict[str, torch.Tensor]) -> None:
         """Sum-all-reduce one module's gradients as flat buckets on the communication stream (RCCL over xGMI: point-to-point links,
         a ring is per-link bound, so few large buckets), while the compute stream carries on with the next module's backward."""
-        if self.world == 1 or not g:
+        if not g:
+            return
+        names = sorted(g)
+        self._comm_bytes += sum(g[n].numel() * g[n].element_size() for n in names)      # what a data-parallel step reduces (counted at any world size)
+        if self.world == 1:
             return
         import torch.distributed as dist
         from .parallel import allreduce_gradients
-        names = sorted(g)
-        self._comm_bytes += sum(g[n].numel() * g[n].element_size() for n in names)
         if g[names[0]].is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
