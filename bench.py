@@ -169,7 +169,7 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become N ranks.  Re-executes this script under torch.distributed.run (one process per
     GPU, rendezvous on 127.0.0.1 at a free port); the re-executed ranks see WORLD_SIZE and take the normal path."""
     import socket
-    if not args.launch_check:
+    if not args.launch_check and not args.share_gpu:
         n_vis = torch.cuda.device_count()
         if n_vis < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} asked for, {n_vis} GPU(s) visible: refusing to report fewer ranks than asked")
@@ -204,11 +204,13 @@ def launch_check(rank, world, local):
         dist.destroy_process_group()
 
 
-def load_traffic():
+def load_traffic(applies):
     """HBM bytes per launch from the PMC passes of this command (profiles/rNN_traffic.json, written by tools/gemm_traffic.py from
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; the newest round's file).  A missing file is reported as such; a file that is there
     and cannot be read is an error — evidence is never dropped silently."""
     import glob
+    if not applies:                              # the PMC passes are of the default command (cfg2, bf16, batch 256): other workloads launch other shapes
+        return None, "the PMC passes (profiles/rNN_traffic.json) are of the default workload (cfg2, bf16, 256 images); not attributed to this one"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
     if not files:
         return None, "no profiles/rNN_traffic.json in the tree"
@@ -240,6 +242,9 @@ def main():
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs: nothing but warm-up + the timed steps (no clock / power sampling loop, no select_layer = -1 steps, no CPU "
                          "baseline), so that two rocprofv3 passes of the same command see the same launches")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL over xGMI) is the measured configuration; gloo + --share-gpu run the multi-rank logic on a one-GPU box (validation only)")
+    ap.add_argument("--share-gpu", action="store_true", help="validation only: every rank uses cuda:0 (RCCL refuses two ranks on one device: use --backend gloo)")
     ap.add_argument("--launch-check", action="store_true", help="CPU-only check of the self-launcher and the rank bookkeeping (gloo)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2",
                     help="cfg2 is the BASELINE.json metric; the others are additional measurements (no cpu_baseline leg)")
@@ -260,6 +265,8 @@ def main():
     if args.launch_check:
         return launch_check(rank, world, local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -267,7 +274,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import setok_amd
     from setok_amd import ops
@@ -374,8 +384,10 @@ def main():
                  "tokens_per_image_mean": round(sum(o2.counts) / len(o2.counts), 2)}
         tower.select_layer = -2
 
-    telemetry = gpu_telemetry(step, local) if rank == 0 and not args.timed_only else None
-    traffic, traffic_note = load_traffic()
+    # clock / power under load: rank 0 re-runs the step while polling rocm-smi — only where the step has no collective (a training step's
+    # all-reduce would wait for ranks that are not stepping)
+    telemetry = gpu_telemetry(step, local) if rank == 0 and not args.timed_only and (world == 1 or trainer is None) else None
+    traffic, traffic_note = load_traffic(args.workload == "cfg2" and args.dtype == "bf16" and B == 256 and args.select_layer == -2)
     if rank == 0:
         gname = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -401,7 +413,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_desc, "batch_per_gpu": B, "global_batch": world * B,
                        "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
-                       "sharding": f"dp{world} (images sharded, no data-path collective)",
+                       "sharding": f"dp{world} (images sharded, no data-path collective)" + ("" if args.backend == "nccl" and not args.share_gpu else
+                                                                                                   f" [VALIDATION RUN: backend {args.backend}, ranks share one GPU: not a scaling number]"),
                        "per_rank": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"]},
             "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<*> (bf16 MFMA GEMM of every large Linear)" if args.dtype == "bf16"
                          else "gemm_f32_kernel (exact-f32 MFMA GEMM, parity mode)",

@@ -12,10 +12,14 @@ from typing import Any, Dict, Iterable
 import torch
 
 
+def _drop_pack_hook(module, incompatible) -> None:
+    module._drop_pack()
+
+
 class PackCacheMixin:
     def _init_pack_cache(self) -> None:
         self._packed: Dict[str, Any] = {}
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_pack())
+        self.register_load_state_dict_post_hook(_drop_pack_hook)                # (a module-level function: lambdas do not pickle)
 
     def _drop_pack(self) -> None:
         self._packed = {}

@@ -60,6 +60,9 @@ class EncodeContext:
             _lib.call("setok_weights_ready", self.handle, st)
         torch.cuda.current_stream().synchronize()                     # the staging copies above read tensors that may die now
 
+    def __deepcopy__(self, memo):
+        raise TypeError("an EncodeContext owns device memory through a C handle and cannot be copied; build a new one from the module")
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

@@ -385,6 +385,14 @@ class SetokTokenizer(nn.Module):
         tokens, counts, idx, score, _ = self._context().encode(x, k, threshold, noise, token_mask)
         return RaggedTokens(tokens, counts), idx, score.reshape(B, 1, -1)
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling (EMA copies, `torch.save(module)`): the library-side context is a handle to device memory owned by THIS
+        object — a copy builds its own on first use."""
+        state = dict(self.__dict__)
+        state.pop("_ctx", None)
+        state.pop("_ctx_params", None)
+        return state
+
     def _context(self):
         """The library-side context holding this module's weights (rebuilt when they, the dtype or the device change)."""
         from .context import EncodeContext

@@ -137,9 +137,10 @@ def test_vitl_tower_fp32_parity(golden_dir):
         sens = O.cluster_sensitivity(x[i], 64, 0.125, 64, ulps=256.0)
         same = idx[i].cpu() == _t(z[f"{i}:idx_cluster"]).long()
         n_diff += int((~same).sum())
-        if sens["centres_certain"]:
-            assert toks[i].shape[0] == _t(z[f"{i}:index_down"]).numel()
-            assert bool((same | ~sens["assign_certain"]).all())
+        # the fixture's decisions are certain at this perturbation (centres all, assignments >= 99 %): no vacuous pass
+        assert sens["centres_certain"] and float(sens["assign_certain"].float().mean()) >= 0.97
+        assert toks[i].shape[0] == _t(z[f"{i}:index_down"]).numel()
+        assert bool((same | ~sens["assign_certain"]).all())
     print("vitl fp32 from pixels: tokens with a different cluster id:", n_diff, "of 512")
 
 
@@ -230,11 +231,10 @@ def test_336_input_576_patches(dt, tol):
         assert toks[i].shape == (16, 64)                         # threshold 0.5 -> fallback to min_cluster_num centres
         if dt == torch.float32:
             sens = O.cluster_sensitivity(ref[i].x, 16, 0.5, 16, ulps=64.0)
-            if sens["centres_certain"]:
-                same = idx[i].cpu() == ref[i].idx_cluster
-                assert bool((same | ~sens["assign_certain"]).all())
-                if bool(same.all()):
-                    assert _rel(toks[i], ref[i].tokens) < TOL
+            assert sens["centres_certain"] and bool(sens["assign_certain"].all())       # seeded inputs chosen so: no vacuous pass
+            same = idx[i].cpu() == ref[i].idx_cluster
+            assert bool(same.all())
+            assert _rel(toks[i], ref[i].tokens) < TOL
 
 
 def test_full_size_batch_invariance_and_properties():
@@ -302,8 +302,9 @@ def test_cfg1_vitb16_fixed_k32_fp32():
     x = feats_ref[0] + O.pos_encoding_2d(14, 14, 768)
     sens = O.cluster_sensitivity(x, 32, 1e9, 32, ulps=256.0)
     same = idx[0].cpu() == ref[0].idx_cluster
-    if sens["centres_certain"]:
-        assert bool((same | ~sens["assign_certain"]).all())
-        if bool(same.all()):
-            assert _rel(toks[0], ref[0].tokens) < TOL
+    # these seeded inputs: centres certain, 195 of 196 assignments certain (checked on the CPU oracle) — the asserts below always run
+    assert sens["centres_certain"] and float(sens["assign_certain"].float().mean()) >= 0.97
+    assert bool((same | ~sens["assign_certain"]).all())
+    if bool(same.all()):
+        assert _rel(toks[0], ref[0].tokens) < TOL
     print("cfg1 ViT-B/16 k=32: tokens with a different cluster id:", int((~same).sum()), "of 196; centres certain:", bool(sens["centres_certain"]))

@@ -175,3 +175,16 @@ def test_head_trainer_says_that_it_trains_without_dropout():
         HeadTrainer(tok, dropout="eval")                           # accepted explicitly: silent
     with pytest.raises(ValueError):
         HeadTrainer(tok, dropout="maybe")
+
+
+def test_tokenizer_copies_do_not_share_the_library_context():
+    """copy.deepcopy / pickle of the module (EMA copies, torch.save of a whole module) must not duplicate the C handle of the encode context."""
+    import copy
+    import pickle
+    tok = _small_tok(0)
+    tok.__dict__["_ctx"] = ("key", object())                       # stands in for a built context (no GPU here)
+    tok.__dict__["_ctx_params"] = list(tok.parameters())
+    for clone in (copy.deepcopy(tok), pickle.loads(pickle.dumps(tok))):
+        assert "_ctx" not in clone.__dict__ and "_ctx_params" not in clone.__dict__
+        assert torch.equal(clone.out.weight, tok.out.weight)
+    assert "_ctx" in tok.__dict__

@@ -139,7 +139,8 @@ def _attn_ref(qkv, H, Dh, scale, offsets):
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("T,H,Dh,nimg", [(17, 4, 16, 3), (257, 16, 64, 2), (65, 2, 512, 2), (197, 12, 64, 1), (324, 16, 48, 2), (33, 3, 48, 3),
-                                          (256, 12, 64, 2), (577, 16, 64, 1), (40, 2, 96, 2)])
+                                          (256, 12, 64, 2), (577, 16, 64, 1), (40, 2, 96, 2),
+                                          (300, 16, 64, 1), (1, 2, 64, 2), (608, 4, 64, 1), (289, 16, 48, 1), (9, 2, 64, 2), (41, 2, 64, 2)])
 def test_attention_uniform(dt, tol, T, H, Dh, nimg):
     qkv = _rand(nimg * T, 3 * H * Dh, seed=8).to(dt)
     ref = _attn_ref(qkv, H, Dh, Dh ** -0.5, [i * T for i in range(nimg + 1)])
@@ -173,7 +174,7 @@ def _cross_ref(q, k, v, H, Dh, scale, q_len, offs):
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("H,Dh,q_len,lens", [(4, 16, 25, [7, 3, 1, 12]), (12, 64, 256, [37, 24, 1, 64, 65]), (12, 64, 324, [40, 33]),
-                                             (2, 64, 5, [130, 2]), (3, 96, 16, [9, 70])])
+                                             (2, 64, 5, [130, 2]), (3, 96, 16, [9, 70]), (12, 64, 33, [50, 17, 1]), (4, 64, 257, [8, 9, 31, 32, 33])])
 def test_cross_attention_ragged(dt, tol, H, Dh, q_len, lens):
     """setok_cross_attention (module.py:283-286,303,342-364): query groups x ragged key segments, k / v as column windows of one
     fused buffer; Dh = 64 in bf16 takes the MFMA kernel, everything else the generic one."""
