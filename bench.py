@@ -413,7 +413,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_desc, "batch_per_gpu": B, "global_batch": world * B,
                        "tokens_per_image": {"mean": round(sum(counts) / len(counts), 2), "min": min(counts), "max": max(counts)},
-                       "sharding": f"dp{world} (images sharded, no data-path collective)" + ("" if args.backend == "nccl" and not args.share_gpu else
+                       "sharding": (f"dp{world} (images sharded; the head's gradients are all-reduced per module in flat buckets, overlapped with the backward pass)"
+                                    if trainer is not None else f"dp{world} (images sharded, no data-path collective)") + ("" if args.backend == "nccl" and not args.share_gpu else
                                                                                                    f" [VALIDATION RUN: backend {args.backend}, ranks share one GPU: not a scaling number]"),
                        "per_rank": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"]},
             "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<*> (bf16 MFMA GEMM of every large Linear)" if args.dtype == "bf16"

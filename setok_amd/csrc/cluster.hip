@@ -164,6 +164,35 @@ struct FArgs {
 
 __device__ inline int f_swz(int row) { return (row >> 1) & 7; }
 
+// The four lanes {l, l + 16, l + 32, l + 48} that own one row meet through gfx950's v_permlane16_swap / v_permlane32_swap: two exchanges in the
+// vector ALU instead of two ds_bpermute round trips through the LDS crossbar (the radix select does one such meeting per bit).  The operand
+// order of every addition is the one of the shuffle form (a + b with the partner's value second or first: the same fp32 result).
+typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+__device__ inline unsigned row4_add(unsigned x) {
+    const u32x2c r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const unsigned y = r[0] + r[1];
+    const u32x2c q = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return q[0] + q[1];
+}
+__device__ inline float row4_addf(float x) {
+    const u32x2c r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const u32x2c q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ inline float row4_maxf(float x) {
+    const u32x2c r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const u32x2c q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ inline float row4_minf(float x) {
+    const u32x2c r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const u32x2c q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return fminf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
 template <bool MASKED>
 __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -296,8 +325,8 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
             mx1 = fmaxf(mx1, ok ? d1 : 0.f);
         }
     }
-    mx0 = fmaxf(mx0, __shfl_xor(mx0, 16, 64)); mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
-    mx1 = fmaxf(mx1, __shfl_xor(mx1, 16, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+    mx0 = row4_maxf(mx0);
+    mx1 = row4_maxf(mx1);
 
     if (stamp) g.tim[2] = __builtin_amdgcn_s_memtime();
     // ---- token_mask (:84-86): masked columns read (global max + 1) everywhere ------------------------------------------------------------
@@ -335,8 +364,8 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
                 mx0 = fmaxf(mx0, ok ? (on ? acc[0][t][e] : fill) : 0.f);
                 mx1 = fmaxf(mx1, ok ? (on ? acc[1][t][e] : fill) : 0.f);
             }
-        mx0 = fmaxf(mx0, __shfl_xor(mx0, 16, 64)); mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
-        mx1 = fmaxf(mx1, __shfl_xor(mx1, 16, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+        mx0 = row4_maxf(mx0);
+        mx1 = row4_maxf(mx1);
     }
     // value of (row m, t, e) as the reference's masked matrix holds it
     auto val = [&](int m, int t, int e) -> float {
@@ -371,8 +400,10 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
                     }
                 q0 += __builtin_popcount(w0); q1 += __builtin_popcount(w1);
             }
-            q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
-            q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+            {
+                const unsigned both = row4_add((unsigned)q0 | ((unsigned)q1 << 16));     // both rows' counts (<= 256 each) in one exchange
+                q0 = (int)(both & 0xffffu); q1 = (int)(both >> 16);
+            }
             if (!done0) { if (q0 <= k - 1) T0 = c0; else if (q0 == k) { T0 = c0; done0 = true; } }
             if (!done1) { if (q1 <= k - 1) T1 = c1; else if (q1 == k) { T1 = c1; done1 = true; } }
             if (__ballot(!(done0 && done1)) == 0ull) break;
@@ -387,10 +418,12 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
                 s0 += in0 ? v0 * v0 : 0.f; q0 += in0;
                 s1 += in1 ? v1 * v1 : 0.f; q1 += in1;
             }
-        s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-        q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
-        q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+        s0 = row4_addf(s0);
+        s1 = row4_addf(s1);
+        {
+            const unsigned both = row4_add((unsigned)q0 | ((unsigned)q1 << 16));
+            q0 = (int)(both & 0xffffu); q1 = (int)(both >> 16);
+        }
         // values tied AT the k-th place (q < k) enter with the k-th value; a row finished early has q == k and its T is a candidate, not a
         // value (its square may overflow: 0 * inf): no tie term then
         const float kth0 = __uint_as_float(T0), kth1 = __uint_as_float(T1);
@@ -424,8 +457,8 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
                 dm1 = fminf(dm1, rj[e] > r1 ? val(1, t, e) : mj[e]);
             }
         }
-        dm0 = fminf(dm0, __shfl_xor(dm0, 16, 64)); dm0 = fminf(dm0, __shfl_xor(dm0, 32, 64));
-        dm1 = fminf(dm1, __shfl_xor(dm1, 16, 64)); dm1 = fminf(dm1, __shfl_xor(dm1, 32, 64));
+        dm0 = row4_minf(dm0);
+        dm1 = row4_minf(dm1);
         if (g4 == 0) {
             const float sc0 = dm0 * r0, sc1 = dm1 * r1;
             s_score[row0] = sc0; s_score[row1] = sc1;
