@@ -186,6 +186,18 @@ __device__ inline float row4_maxf(float x) {
     const u32x2c q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
+__device__ inline unsigned row4_minu(unsigned x) {
+    const u32x2c r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const unsigned y = min(r[0], r[1]);
+    const u32x2c q = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return min(q[0], q[1]);
+}
+__device__ inline unsigned row4_maxu(unsigned x) {
+    const u32x2c r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const unsigned y = max(r[0], r[1]);
+    const u32x2c q = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return max(q[0], q[1]);
+}
 __device__ inline float row4_minf(float x) {
     const u32x2c r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     const float y = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -383,16 +395,50 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
         // remaining low bits only matter when values tie at the k-th place.  Typically ~18 of the 31 steps.
         unsigned T0 = 0, T1 = 0;
         bool done0 = false, done1 = false;
-        for (int bit = 30; bit >= 0; --bit) {
+        int top = 30;
+        if constexpr (!MASKED) {
+            // The leading bits the row's values (the self-distance 0 aside) have in common are decided without counting: where the common
+            // prefix has a 1 only the self-distance lies below the candidate (1 <= k - 1), where it has a 0 all 256 values do (> k - 1) —
+            // T starts as the prefix and the steps start at the highest bit in which two values of any row of the wave differ.  Distances of
+            // high-dimensional features concentrate (d ~ sqrt(2) sigma): typically 8-9 of the ~18 steps go.  Exact for any input: rows
+            // with a second exact zero, or columns beyond N (+inf), simply have no common prefix.
+            if (k >= 2) {
+                unsigned lo0 = 0xffffffffu, lo1 = 0xffffffffu, hi0 = 0u, hi1 = 0u;
+                const bool self_lane = g4 == (l15 >> 2);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const bool ts0 = t == 2 * wave, ts1 = t == 2 * wave + 1;           // wave-uniform: the 16-column tile that holds the diagonal
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned p0 = __float_as_uint(acc[0][t][e]), p1 = __float_as_uint(acc[1][t][e]);
+                        hi0 = max(hi0, p0); hi1 = max(hi1, p1);
+                        if (ts0) { if (self_lane && e == (l15 & 3)) p0 = 0xffffffffu; }
+                        if (ts1) { if (self_lane && e == (l15 & 3)) p1 = 0xffffffffu; }
+                        lo0 = min(lo0, p0); lo1 = min(lo1, p1);
+                    }
+                }
+                lo0 = row4_minu(lo0); lo1 = row4_minu(lo1); hi0 = row4_maxu(hi0); hi1 = row4_maxu(hi1);
+                const unsigned df0 = lo0 ^ hi0, df1 = lo1 ^ hi1;
+                const int hb0 = df0 ? 31 - __builtin_clz(df0) : -1, hb1 = df1 ? 31 - __builtin_clz(df1) : -1;
+                T0 = hb0 >= 0 ? (hb0 >= 31 ? 0u : lo0 & ~((2u << hb0) - 1u)) : lo0;
+                T1 = hb1 >= 0 ? (hb1 >= 31 ? 0u : lo1 & ~((2u << hb1) - 1u)) : lo1;
+                const int hbm = max(hb0, hb1);
+                top = 30;
+                while (top > 0 && __ballot(hbm >= top) == 0ull) --top;
+            }
+        }
+        for (int bit = top; bit >= 0; --bit) {
             const unsigned c0 = T0 | (1u << bit), c1 = T1 | (1u << bit);
             // #values < candidate: the sign bit of (pattern - candidate) (both below 2^31) is shifted into a 32-bit register per element
             // (v_sub + v_alignbit: no carry flag, hence none of the wait states a v_cmp / v_addc chain needs) and popcounted per 32 elements
+            // Eight elements per accumulator register, sixteen independent registers: a single register per 32 elements is a serial chain of
+            // dependent v_alignbit (measured: ~8 cycles per instruction, 4 k cycles per bit with two waves per SIMD).
             int q0 = 0, q1 = 0;
 #pragma unroll
-            for (int th = 0; th < 2; ++th) {
+            for (int tp = 0; tp < 8; ++tp) {
                 unsigned w0 = 0, w1 = 0;
 #pragma unroll
-                for (int t = th * 8; t < th * 8 + 8; ++t)
+                for (int t = tp * 2; t < tp * 2 + 2; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         w0 = __builtin_amdgcn_alignbit(w0, __float_as_uint(val(0, t, e)) - c0, 31);
