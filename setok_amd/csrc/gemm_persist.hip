@@ -368,13 +368,13 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         const char* r_wave = reinterpret_cast<const char*>(g.res + (RESK ? wave_elem : 0));
         const unsigned lane_off = (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
         const unsigned row8 = (unsigned)g.ldc * 16u;                          // bytes between consecutive `it` (8 rows)
-        bf16x8 rv[2][4];
+        bf16x8 rv[1][4];
         auto load_residual = [&](auto int_tag, int h) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
                 if (decltype(int_tag)::value || (grow < g.M && col_ok))
-                    rv[h & 1][it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
+                    rv[0][it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
             }
         };
         s_barrier_lgkm();
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[h & 1][it][e]);
+                        for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[0][it][e]);
                 }
                 if (h == 0) {
                     asm volatile("" ::: "memory");
