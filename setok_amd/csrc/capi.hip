@@ -39,26 +39,51 @@ extern "C" int setok_device_info(char* name_host, int name_cap, int* cu_count_ho
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { int kind, cls; double work, bytes; hipEvent_t e0, e1; };
+struct ProfRec { int kind, cls; double work, bytes; hipEvent_t e0, e1; bool attach, started, stopped; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 volatile int g_prof_on = 0;
+thread_local std::vector<int> g_open;               // indices of this thread's open attach-scopes, innermost last
 }  // namespace
 
 bool setok_prof_on() { return g_prof_on != 0; }
 
-int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes) {
-    ProfRec r{kind, cls, work, bytes, nullptr, nullptr};
+int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes, bool attach) {
+    ProfRec r{kind, cls, work, bytes, nullptr, nullptr, attach, false, false};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
-    (void)hipEventRecord(r.e0, s);
+    if (!attach) { (void)hipEventRecord(r.e0, s); r.started = true; }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
-    return (int)g_prof.size() - 1;
+    const int idx = (int)g_prof.size() - 1;
+    if (attach) g_open.push_back(idx);
+    return idx;
+}
+
+hipEvent_t setok_prof_start_event() {
+    if (g_open.empty()) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const int idx = g_open.back();
+    if (idx >= (int)g_prof.size() || g_prof[idx].started) return nullptr;      // (the records were reset under an open scope: nothing to attach to)
+    g_prof[idx].started = true;
+    return g_prof[idx].e0;
+}
+
+hipEvent_t setok_prof_stop_event() {
+    if (g_open.empty()) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const int idx = g_open.back();
+    if (idx >= (int)g_prof.size() || g_prof[idx].stopped) return nullptr;
+    g_prof[idx].stopped = true;
+    return g_prof[idx].e1;
 }
 
 void setok_prof_end(hipStream_t s, int index) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (index >= 0 && index < (int)g_prof.size()) (void)hipEventRecord(g_prof[index].e1, s);
+    if (!g_open.empty() && g_open.back() == index) g_open.pop_back();
+    if (index < 0 || index >= (int)g_prof.size()) return;
+    ProfRec& r = g_prof[index];
+    if (!r.started) { r.kind = -1; (void)hipEventRecord(r.e0, s); r.started = true; }   // an attach-scope whose path launched the plain way: no start time, the record is dropped
+    if (!r.stopped) { (void)hipEventRecord(r.e1, s); r.stopped = true; }
 }
 
 extern "C" int setok_profile_start(void) {
@@ -73,14 +98,15 @@ extern "C" int setok_profile_start(void) {
 extern "C" int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* ms, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = 0;
-    int n = 0;
+    int n = 0, dropped = 0;
     for (auto& r : g_prof) {
         float t = 0.f;
+        if (r.kind < 0) ++dropped;
         const bool ok = hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess;
-        if (ok && n < cap && kind && cls && work && bytes && ms) { kind[n] = r.kind; cls[n] = r.cls; work[n] = r.work; bytes[n] = r.bytes; ms[n] = t; ++n; }
+        if (ok && r.kind >= 0 && n < cap && kind && cls && work && bytes && ms) { kind[n] = r.kind; cls[n] = r.cls; work[n] = r.work; bytes[n] = r.bytes; ms[n] = t; ++n; }
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
-    const int total = (int)g_prof.size();
+    const int total = (int)g_prof.size() - dropped;
     g_prof.clear();
     return n < total && cap >= total ? -1 : n;
 }

@@ -819,8 +819,10 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
     const int rows = B * N;
     const float sqrtC = (float)sqrt((double)C);
     // algorithmic bytes: x read once; idx_cluster (int64), score (fp32), index_down (int64, <= N) written
-    SetokProfScope prof(s, SETOK_PROF_CLUSTER, 0, 2.0 * B * (double)N * N * C, (double)B * ((double)N * C * (dtype == SETOK_BF16 ? 2 : 4) + N * 8.0 + N * 4.0 + N * 8.0));
-    if (dtype == SETOK_BF16 && C % 64 == 0 && N <= FN && !fused_disabled()) {
+    const bool one_launch = dtype == SETOK_BF16 && C % 64 == 0 && N <= FN && !fused_disabled();
+    SetokProfScope prof(s, SETOK_PROF_CLUSTER, 0, 2.0 * B * (double)N * N * C, (double)B * ((double)N * C * (dtype == SETOK_BF16 ? 2 : 4) + N * 8.0 + N * 4.0 + N * 8.0),
+                        one_launch);      // the single launch carries the profiler's timestamps itself
+    if (one_launch) {
         // the whole call in one launch, one workgroup per image, no workspace (the BASELINE configuration)
         static SetokDeviceOnce once_f;
         if (!once_f.run([] { return hipFuncSetAttribute((const void*)dpc_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) == hipSuccess &&
@@ -833,7 +835,8 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
         if (timing && !tim && hipMalloc(&tim, 8 * 8) != hipSuccess) tim = nullptr;
         FArgs a{(const bf16*)x, noise, token_mask, idx_cluster, score, index_down, counts, N, C, k, min_cluster_num, threshold, sqrtC, 1.0f / sqrtC,
                 mant == 0.5f ? 1 : 0, timing ? tim : nullptr};
-        if (token_mask) dpc_fused_kernel<true><<<B, 512, F_LDS, s>>>(a); else dpc_fused_kernel<false><<<B, 512, F_LDS, s>>>(a);
+        const hipEvent_t e0 = setok_prof_start_event(), e1 = setok_prof_stop_event();
+        if (token_mask) setok_launch(dpc_fused_kernel<true>, dim3(B), dim3(512), F_LDS, s, e0, e1, a); else setok_launch(dpc_fused_kernel<false>, dim3(B), dim3(512), F_LDS, s, e0, e1, a);
         SETOK_CHECK_LAUNCH("setok_cluster_dpc_knn(fused)");
         if (timing && tim) {
             unsigned long long h[8];

@@ -36,13 +36,29 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // work of these launches / their event durations, measured where the launches really happen — inside the library, whichever host calls it.
 enum { SETOK_PROF_GEMM_BF16 = 0, SETOK_PROF_GEMM_F32 = 1, SETOK_PROF_CLUSTER = 2 };
 bool setok_prof_on();
-int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes);    // cls: act | residual << 2 | layernorm << 3; returns the record's index
+int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes, bool attach);    // cls: act | residual << 2 | layernorm << 3; returns the record's index
 void setok_prof_end(hipStream_t s, int index);
+// A scope opened with attach = true does not put marker events on the stream: its first launch takes setok_prof_start_event() and its last
+// setok_prof_stop_event() through hipExtLaunchKernelGGL, so the timestamps are the dispatches' own (start of the first kernel, end of the
+// last) and no barrier packet sits between the launches — marker events around each of the ~110 GEMM calls of a cfg2 step cost 0.55 ms of a
+// 45.7 ms step.  Whatever such a scope did not hand out by its end is recorded as a marker then (a path that launches the plain way).
+hipEvent_t setok_prof_start_event();                 // of the innermost open attach-scope of this thread, once; else nullptr
+hipEvent_t setok_prof_stop_event();
 struct SetokProfScope {                              // scopes may nest (the fp32 clustering calls setok_linear for its Gram matrices)
     hipStream_t s; int idx;
-    SetokProfScope(hipStream_t s_, int kind, int cls, double work, double bytes) : s(s_), idx(setok_prof_on() ? setok_prof_begin(s_, kind, cls, work, bytes) : -1) {}
+    SetokProfScope(hipStream_t s_, int kind, int cls, double work, double bytes, bool attach = false)
+        : s(s_), idx(setok_prof_on() ? setok_prof_begin(s_, kind, cls, work, bytes, attach) : -1) {}
     ~SetokProfScope() { if (idx >= 0) setok_prof_end(s, idx); }
 };
+// kernel<<<grid, block, lds, s>>>(args...), with the dispatch's own start / stop timestamps going to the events when there are any
+#if defined(__HIPCC__)
+#include <hip/hip_ext.h>
+template <typename K, typename... A>
+static inline void setok_launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1, A... args) {
+    if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, s, e0, e1, 0u, args...);
+    else kernel<<<grid, block, lds, s>>>(args...);
+}
+#endif
 
 // ---- per-device one-time setup (host) ---------------------------------------------------------
 // hipFuncSetAttribute (dynamic-LDS limit) is a property of (function, DEVICE); a process-wide `static bool` would skip it on a second
