@@ -328,8 +328,11 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool ok = t * 16 + 4 * g4 + e < N;
-            float d0 = sqrtf(fmaxf((n0 + nj[e]) - 2.0f * acc[0][t][e], 0.f));
-            float d1 = sqrtf(fmaxf((n1 + nj[e]) - 2.0f * acc[1][t][e], 0.f));
+            // v_sqrt_f32 itself (1 ulp): sqrtf() wraps it in a denormal rescale and two fma fix-ups for correct rounding — 17 instructions per
+            // element, most of this phase — which the bf16 mode's contract (decisions equal wherever 64 ulps of d^2 cannot flip them) does not
+            // need.  D stays symmetric bit for bit: the same instruction on the same operands.
+            float d0 = __builtin_amdgcn_sqrtf(fmaxf((n0 + nj[e]) - 2.0f * acc[0][t][e], 0.f));
+            float d1 = __builtin_amdgcn_sqrtf(fmaxf((n1 + nj[e]) - 2.0f * acc[1][t][e], 0.f));
             if (g.scale_by_mul) { d0 *= g.inv_sqrtC; d1 *= g.inv_sqrtC; } else { d0 = d0 / g.sqrtC; d1 = d1 / g.sqrtC; }
             acc[0][t][e] = ok ? d0 : INF;                                   // columns beyond N: never nearest, never a centre
             acc[1][t][e] = ok ? d1 : INF;
