@@ -60,7 +60,7 @@ WORKLOADS = {
     "cfg4": (336, 128, False, "cfg4: ViT-L/14 336^2 = 576 patches (tower frozen), dyn-k, batch 128 per GPU; TRAINING STEP of the head (37.8 M "
                                "parameters: inner_encoder, inter_encoder, out): tower + head forward with saved activations, hand-written backward "
                                "from a synthetic dL/dtokens, per-module RCCL gradient all-reduce overlapped with the backward pass, AdamW on fp32 "
-                               "master weights; eval-mode arithmetic (the reference's proj_drop = 0.2 masks are not applied)"),
+                               "master weights; training-mode arithmetic: the reference's proj_drop = 0.2 masks at the three dropout sites of both Blocks (seeded, regenerated in the backward pass)"),
     "cfg5": (224, 32, False, "cfg5: full Setokim forward at Vicuna-7B dims (32 layers, hidden 4096, 32 heads x 128, SwiGLU 11008, vocab 32000; random-init "
                               "bf16 weights): 32 images -> SeTok encode (cfg2 model) -> mm_in_projector -> splice into 512-token prompts -> LLM prefill -> "
                               "logits at every position -> language-model loss over the answer part (setokim_llama.py:94-160; the diffusion term is out of scope)"),
@@ -320,7 +320,7 @@ def main():
     trainer = None
     if args.workload == "cfg4":
         from setok_amd.training import HeadTrainer
-        trainer = HeadTrainer(tok, lr=1e-5, weight_decay=0.0, dropout="eval")    # eval-mode arithmetic: no dropout masks (stated in the workload text)
+        trainer = HeadTrainer(tok, lr=1e-5, weight_decay=0.0, dropout="train", dropout_seed=1234)    # the reference's training objective: proj_drop masks active
 
     def step():
         if llm is not None:

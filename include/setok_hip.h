@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 3
+#define SETOK_ABI_VERSION 4
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -121,6 +121,14 @@ int setok_layernorm(void* stream, int dtype, const void* x, const float* gamma, 
 /* y = act(x) elementwise (n elements) — nn.GELU placed after a LayerNorm in the `mlp{N}x_gelu_Norm`
  * projector (multimodal_projector/builder.py:48-58), where it cannot be fused into a GEMM epilogue. */
 int setok_activation(void* stream, int dtype, const void* x, void* y, int64_t n, int act);
+
+/* Training-mode dropout of the head's Block: nn.Dropout(proj_drop) after the attention projection (module.py:59,72), after the Mlp's activation
+ * and after its fc2 (module.py:36,44,45); proj_drop = 0.2 by default (tokenizer.py:26).
+ *   y[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0),   keep_i = hash(seed, offset + i) >= p * 2^32     (residual may be NULL; y may alias x or residual)
+ * The mask is a pure function of (seed, offset + i) (a SplitMix64 finaliser over the counter): the backward pass applies the same call to the
+ * incoming gradient instead of storing masks, and a step is reproducible from its seed.  Bernoulli(1 - p) like the reference's masks, not
+ * bit-equal to torch's Philox stream.  n elements of `dtype`. */
+int setok_dropout(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint64_t offset);
 
 /* Block-diagonal ("varlen") multi-head self-attention over contiguous row segments.
  * qkv: (rows, 3*H*Dh) laid out [q | k | v], heads inside — the layout both the fused `qkv` Linear

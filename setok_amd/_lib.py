@@ -45,6 +45,7 @@ SIGNATURES = {
     "setok_linear_ln": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i],
     "setok_layernorm": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f],
     "setok_activation": [_vp, _i, _vp, _vp, _i64, _i],
+    "setok_dropout": [_vp, _i, _vp, _vp, _vp, _i64, _f, C.c_uint64, C.c_uint64],
     "setok_attention": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f],
     "setok_cross_attention": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _i, _i, _f],
     "setok_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i],

@@ -186,3 +186,41 @@ extern "C" int setok_activation(void* stream, int dtype, const void* x, void* y,
     SETOK_CHECK_LAUNCH("setok_activation");
     return SETOK_OK;
 }
+
+// ---- training-mode dropout of the head's Block (module.py:36,44,45,59,72: nn.Dropout(proj_drop) after the attention projection, after the Mlp's
+// activation and after its fc2; proj_drop = 0.2 by default, tokenizer.py:26) -------------------------------------------------------------------
+// out[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0),  keep_i = hash(seed, offset + i) >= p * 2^32.
+// Counter-based: the mask of element i is a pure function of (seed, offset + i) — the backward pass regenerates it instead of storing it
+// (d/dx = the same mask and scale on the incoming gradient), and a step is reproducible from its seed.  The generator is a SplitMix64
+// finaliser over the counter, not torch's Philox stream: masks are Bernoulli(1 - p) like the reference's, not bit-equal to them.
+__device__ inline bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned thresh) {
+    unsigned long long z = seed + ctr * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= thresh;
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* x, const T* res, T* y, int64_t n, float scale, unsigned thresh, unsigned long long seed, unsigned long long offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = dropout_keep(seed, offset + (unsigned long long)i, thresh) ? Elem<T>::ld(x + i) * scale : 0.f;
+        Elem<T>::st(y + i, res ? Elem<T>::ld(res + i) + v : v);
+    }
+}
+
+extern "C" int setok_dropout(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint64_t offset) {
+    SETOK_CHECK_ARG(x && y && n >= 0, "setok_dropout: bad operand");
+    SETOK_CHECK_ARG(p >= 0.f && p < 1.f, "setok_dropout: p=%g outside [0, 1)", (double)p);
+    if (n == 0) return SETOK_OK;
+    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    const double t = (double)p * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    const float scale = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) dropout_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, (const bf16*)residual, (bf16*)y, n, scale, thresh, seed, offset);
+    else if (dtype == SETOK_F32) dropout_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)residual, (float*)y, n, scale, thresh, seed, offset);
+    else return setok_fail(SETOK_EINVAL, "setok_dropout: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_dropout");
+    return SETOK_OK;
+}

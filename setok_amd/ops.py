@@ -262,6 +262,17 @@ def activation(x: Tensor, act: int, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def dropout(x: Tensor, p: float, seed: int, offset: int = 0, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """out = residual + x * mask / (1 - p), mask_i a pure function of (seed, offset + i) (include/setok_hip.h: setok_dropout).  Applying the same
+    call (no residual) to an incoming gradient is the backward pass."""
+    if out is None:
+        out = torch.empty_like(x)
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape and (residual is None or (residual.shape == x.shape and residual.is_contiguous()))
+    _lib.call("setok_dropout", _stream(), _code(x.dtype), _p(x), _p(residual), _p(out), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+              int(offset) & 0xFFFFFFFFFFFFFFFF)
+    return out
+
+
 # ---- prepare_inputs_labels_for_multimodal (setokim_arch.py:213-355) --------------------------------------------------------
 def splice_lengths(input_ids: Tensor, attention_mask: Optional[Tensor], img_offsets: Tensor, n_images: int, image_token_index: int,
                    max_length: int, vocab: int = 0) -> Tuple[Tensor, Tensor, Tensor]:

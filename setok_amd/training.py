@@ -54,21 +54,46 @@ def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[s
 # ----------------------------------------------------------------------------------------------------------------------------
 # Block (module.py:76-100): `depth` attention sub-layers sharing ONE norm1, then norm2 + Mlp
 # ----------------------------------------------------------------------------------------------------------------------------
-def block_forward_train(blk: Block, x: torch.Tensor, seg_offsets: torch.Tensor, n_segs: int, seg_bound: int):
+SITE_STRIDE = 1 << 40          # elements a dropout site may hold: every site draws from its own range of the counter
+
+
+class DropSpec:
+    """Training-mode dropout of a Block (module.py:36,44,45,59,72): rate p = the module's proj_drop, `seed` of the step, `site0` = the first of
+    the depth + 2 counter ranges this Block owns (attention projection of layer i: site0 + i; Mlp activation: site0 + depth; Mlp fc2:
+    site0 + depth + 1)."""
+
+    def __init__(self, p: float, seed: int, site0: int):
+        self.p, self.seed, self.site0 = float(p), int(seed), int(site0)
+
+    def offset(self, site: int) -> int:
+        return (self.site0 + site) * SITE_STRIDE
+
+
+def block_forward_train(blk: Block, x: torch.Tensor, seg_offsets: torch.Tensor, n_segs: int, seg_bound: int, drop: Optional[DropSpec] = None):
     pk = blk._pack()
     H, Dh = blk.num_heads, blk.dim // blk.num_heads
-    ctx = dict(x=[], y=[], qkv=[], o=[], seg=(seg_offsets, n_segs, seg_bound))
-    for a in pk["attn"]:
+    depth = len(pk["attn"])
+    ctx = dict(x=[], y=[], qkv=[], o=[], seg=(seg_offsets, n_segs, seg_bound), drop=drop)
+    for i, a in enumerate(pk["attn"]):
         y = ops.layernorm(x, *pk["n1"], pk["eps"])
         qkv = ops.linear(y, a["wqkv"], a["bqkv"])
         o = ops.attention(qkv, H, Dh, a["scale"], seg_len=seg_bound, seg_offsets=seg_offsets, n_segs=n_segs)
         ctx["x"].append(x); ctx["y"].append(y); ctx["qkv"].append(qkv); ctx["o"].append(o)
-        x = ops.linear(o, a["wproj"], a["bproj"], residual=x)
+        if drop is None:
+            x = ops.linear(o, a["wproj"], a["bproj"], residual=x)
+        else:                                                        # x + proj_drop(proj(o))  (module.py:71-72,96)
+            pr = ops.linear(o, a["wproj"], a["bproj"])
+            x = ops.dropout(pr, drop.p, drop.seed, drop.offset(i), residual=x, out=pr)
     y2 = ops.layernorm(x, *pk["n2"], pk["eps"])
     pre = ops.linear(y2, pk["w1"], pk["b1"])
     u = ops.activation(pre, ops.ACT_GELU_ERF)                     # separate from the GEMM here: the backward pass needs `pre`
-    out = ops.linear(u, pk["w2"], pk["b2"], residual=x)
-    ctx.update(xd=x, y2=y2, pre=pre, u=u)
+    if drop is None:
+        out = ops.linear(u, pk["w2"], pk["b2"], residual=x)
+    else:                                                            # x + drop(fc2(drop(act(fc1)))))  (module.py:40-45,98)
+        u = ops.dropout(u, drop.p, drop.seed, drop.offset(depth), out=u)
+        f = ops.linear(u, pk["w2"], pk["b2"])
+        out = ops.dropout(f, drop.p, drop.seed, drop.offset(depth + 1), residual=x, out=f)
+    ctx.update(xd=x, y2=y2, pre=pre, u=u)                        # u: what fc2 read (after its dropout)
     return out, ctx
 
 
@@ -78,20 +103,25 @@ def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[st
     H, Dh = blk.num_heads, blk.dim // blk.num_heads
     C = blk.dim
     seg_offsets, n_segs, seg_bound = ctx["seg"]
+    drop: Optional[DropSpec] = ctx.get("drop")
     dev = g.device
-    # Mlp: out = xd + fc2(gelu(fc1(norm2(xd))))
-    du = linear_bwd(ctx["u"], pk["w2"], g, grads, prefix + "mlp.fc2")
+    depth = len(pk["attn"])
+    # Mlp: out = xd + drop(fc2(drop(gelu(fc1(norm2(xd))))))  — a dropout's backward is the same mask and scale on the gradient
+    gf = g if drop is None else ops.dropout(g, drop.p, drop.seed, drop.offset(depth + 1))
+    du = linear_bwd(ctx["u"], pk["w2"], gf, grads, prefix + "mlp.fc2")
+    if drop is not None:
+        du = ops.dropout(du, drop.p, drop.seed, drop.offset(depth), out=du)
     dpre = ops.gelu_bwd(ctx["pre"], du)
     dy2 = linear_bwd(ctx["y2"], pk["w1"], dpre, grads, prefix + "mlp.fc1")
     g2w = torch.empty((C,), dtype=torch.float32, device=dev); g2b = torch.empty_like(g2w)
     g = ops.layernorm_bwd(ctx["xd"], dy2, pk["n2"][0], pk["eps"], g2w, g2b, accumulate=False, res=g)      # dL/dxd = g + LN2'(dy2)
     grads[prefix + "norm2.weight"], grads[prefix + "norm2.bias"] = g2w, g2b
     g1w = torch.zeros((C,), dtype=torch.float32, device=dev); g1b = torch.zeros_like(g1w)                # shared norm1 accumulates
-    depth = len(pk["attn"])
     for i in reversed(range(depth)):
         a = pk["attn"][i]
         lp = prefix + f"layers.{i}.1."
-        do = linear_bwd(ctx["o"][i], a["wproj"], g, grads, lp + "proj")
+        gp = g if drop is None else ops.dropout(g, drop.p, drop.seed, drop.offset(i))
+        do = linear_bwd(ctx["o"][i], a["wproj"], gp, grads, lp + "proj")
         dqkv = ops.attention_bwd(ctx["qkv"][i], ctx["o"][i], do, H, Dh, a["scale"], seg_bound, seg_offsets, n_segs)
         dy = linear_bwd(ctx["y"][i], a["wqkv"], dqkv, grads, lp + "qkv")
         last = i == 0 and not need_dx
@@ -104,8 +134,10 @@ def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[st
 # the head
 # ----------------------------------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, noise=None):
-    """tokenizer.py:162-180 for a batch, keeping what the backward pass needs.  Returns (tokens: RaggedTokens, ctx)."""
+def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, noise=None, dropout_seed: Optional[int] = None):
+    """tokenizer.py:162-180 for a batch, keeping what the backward pass needs.  Returns (tokens: RaggedTokens, ctx).  `dropout_seed`: run the two
+    Blocks in TRAINING mode — nn.Dropout(proj_drop) at its three sites (module.py:36,44,45,59,72) with masks drawn from this seed; None = eval-mode
+    arithmetic."""
     tower = tok.image_feature_encoder
     skip = 1 if tower.select_feature == "patch" else 0
     C = hidden_rows.shape[-1]
@@ -119,9 +151,19 @@ def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k
     counts_h = counts.cpu().tolist()
     total = int(sum(counts_h))
     hs = ops.gather_rows(x, perm)
-    inner_out, inner_ctx = block_forward_train(tok.inner_encoder, hs, seg_offsets, total, N)
+    d_inner = d_inter = None
+    if dropout_seed is not None:
+        for b in (tok.inner_encoder, tok.inter_encoder):
+            if getattr(b, "attn_drop_p", 0.0) > 0.0:
+                raise NotImplementedError("training-mode attn_drop (dropout on the attention probabilities, module.py:68) is not implemented; the reference's default is 0.0")
+        n_inner = len(tok.inner_encoder._pack()["attn"]) + 2
+        if tok.inner_encoder.proj_drop_p > 0.0:
+            d_inner = DropSpec(tok.inner_encoder.proj_drop_p, dropout_seed, 0)
+        if tok.inter_encoder.proj_drop_p > 0.0:
+            d_inter = DropSpec(tok.inter_encoder.proj_drop_p, dropout_seed, n_inner)
+    inner_out, inner_ctx = block_forward_train(tok.inner_encoder, hs, seg_offsets, total, N, d_inner)
     group = ops.segment_mean(inner_out, seg_offsets, img_offsets[B:], total)
-    inter_out, inter_ctx = block_forward_train(tok.inter_encoder, group, img_offsets, B, max(counts_h))
+    inter_out, inter_ctx = block_forward_train(tok.inter_encoder, group, img_offsets, B, max(counts_h), d_inter)
     w_out = tok.out.weight.detach().contiguous()
     tokens = ops.linear(inter_out, w_out, tok.out.bias.detach().float().contiguous())
     ctx = dict(inner=inner_ctx, inter=inter_ctx, inter_out=inter_out, w_out=w_out, seg_offsets=seg_offsets, img_offsets=img_offsets,
@@ -164,21 +206,27 @@ class HeadTrainer:
     """
 
     def __init__(self, tok: SetokTokenizer, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, process_group=None, bucket_bytes: int = 64 << 20, dropout: str = "warn"):
+                 weight_decay: float = 0.0, process_group=None, bucket_bytes: int = 64 << 20, dropout: str = "warn", dropout_seed: int = 0):
         """`dropout`: the reference trains the head with Attention.proj_drop and both Mlp.drop at `proj_drop` (0.2 by default,
-        tokenizer.py:23, module.py:36,44,59,72).  This training step runs the head's EVAL-mode arithmetic — no dropout masks in the forward
-        or backward pass — i.e. it optimises the unregularised objective.  "warn" (default) says so once when the module was built with a
-        non-zero rate, "error" refuses, "eval" accepts silently (the caller knows: benchmarks, parity tests against eval-mode gradients)."""
+        tokenizer.py:26, module.py:36,44,45,59,72).
+          "train": the masks are active in forward() and backward() (setok_dropout: counter-based, seeded by `dropout_seed`, the step number and
+                   the data-parallel rank; attn_drop > 0 is not implemented and raises) — the reference's training objective;
+          "eval":  eval-mode arithmetic, the unregularised objective, accepted silently (benchmarks, parity tests against eval-mode gradients);
+          "warn" (default) / "error": eval-mode arithmetic, but say so once / refuse when the module was built with a non-zero rate."""
         rates = {n: (getattr(b, "proj_drop_p", 0.0), getattr(b, "attn_drop_p", 0.0)) for n, b in (("inner_encoder", tok.inner_encoder), ("inter_encoder", tok.inter_encoder))}
-        if dropout not in ("warn", "error", "eval"):
-            raise ValueError(f"dropout must be 'warn', 'error' or 'eval', got {dropout!r}")
-        if any(p > 0.0 or a > 0.0 for p, a in rates.values()) and dropout != "eval":
+        if dropout not in ("warn", "error", "eval", "train"):
+            raise ValueError(f"dropout must be 'train', 'warn', 'error' or 'eval', got {dropout!r}")
+        if dropout == "train" and any(a > 0.0 for _, a in rates.values()):
+            raise NotImplementedError(f"HeadTrainer(dropout='train'): attn_drop > 0 (dropout on the attention probabilities, module.py:68) is not implemented: {rates}")
+        if any(p > 0.0 or a > 0.0 for p, a in rates.values()) and dropout not in ("eval", "train"):
             msg = (f"HeadTrainer runs the head without dropout (eval-mode arithmetic), but the module was built with (proj_drop, attn_drop) = {rates}: "
-                   "the reference trains with these masks active (module.py:29-73); pass dropout='eval' to accept the unregularised objective")
+                   "the reference trains with these masks active (module.py:29-73); pass dropout='train' for them, or dropout='eval' to accept the unregularised objective")
             if dropout == "error":
                 raise NotImplementedError(msg)
             import warnings
             warnings.warn(msg, stacklevel=2)
+        self.dropout = dropout
+        self.dropout_seed = int(dropout_seed)
         self.tok = tok
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.group = process_group
@@ -229,7 +277,16 @@ class HeadTrainer:
         hidden = self.tok.image_feature_encoder.hidden_rows(images)
         if hidden.dtype != self.tok.dtype:
             hidden = hidden.to(self.tok.dtype)
-        return head_forward_train(self.tok, hidden, B, k, threshold, noise)
+        return head_forward_train(self.tok, hidden, B, k, threshold, noise, dropout_seed=self.step_seed() if self.dropout == "train" else None)
+
+    def step_seed(self) -> int:
+        """The dropout seed of the step about to run: a function of (dropout_seed, step number, data-parallel rank) — every rank and every step
+        draws different masks, and a resumed run (self.t restored) repeats them."""
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+        z = (self.dropout_seed * 0x9E3779B97F4A7C15 + self.t * 0xBF58476D1CE4E5B9 + rank * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 29
+        return (z * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF
 
     @torch.no_grad()
     def backward(self, ctx, dtokens: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -173,6 +173,7 @@ def test_head_trainer_says_that_it_trains_without_dropout():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         HeadTrainer(tok, dropout="eval")                           # accepted explicitly: silent
+        assert HeadTrainer(tok, dropout="train", dropout_seed=3).step_seed() == HeadTrainer(tok, dropout="train", dropout_seed=3).step_seed()   # the masks ARE applied: nothing to warn about
     with pytest.raises(ValueError):
         HeadTrainer(tok, dropout="maybe")
 

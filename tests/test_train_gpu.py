@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     import setok_amd
     from setok_amd import ops, SetokTokenizer
-    from setok_amd.training import HeadTrainer, head_backward, head_forward_train
+    from setok_amd.training import HeadTrainer, head_backward, head_forward_train, SITE_STRIDE
 
 DEV = "cuda"
 
@@ -198,6 +198,119 @@ def test_trainer_step_matches_torch_adamw(golden_dir):
     hc = O.HeadConfig(hidden_dim=64, token_feat_dim=96, min_cluster_num=8, threshold=0.5, nheads=2, dim_feedforward=128)
     want = O.head_forward(ref_sd, hc, hidden[1:65], None, thr).tokens
     assert _rel(t2[0], want) < 1e-4
+
+
+# ---- training-mode dropout (module.py:36,44,45,59,72) ------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dropout_op_is_a_seeded_bernoulli_mask(dt):
+    """setok_dropout: keep-rate 1 - p (within 5 sigma), survivors scaled by 1 / (1 - p), a pure function of (seed, offset + i) — the same call on
+    a gradient is the backward pass —, residual form, in-place form."""
+    n, p = 1 << 20, 0.2
+    x = (_rand(n, seed=3) + 3.0).to(dt).to(DEV)
+    y = ops.dropout(x, p, seed=77, offset=5)
+    kept = y != 0
+    rate = float(kept.float().mean())
+    assert abs(rate - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
+    assert torch.equal(y[kept], (x.float()[kept] * (1.0 / (1.0 - p))).to(dt))
+    assert torch.equal(ops.dropout(x, p, seed=77, offset=5), y)                                  # deterministic
+    assert not torch.equal(ops.dropout(x, p, seed=78, offset=5) != 0, kept)                      # another seed, another mask
+    m0 = ops.dropout(torch.ones(n, device=DEV), p, seed=77, offset=0) != 0
+    assert torch.equal(m0[5:], kept[:-5])                                                        # the counter is offset + i
+    r = _rand(n, seed=4).to(dt).to(DEV)
+    z = ops.dropout(x, p, seed=77, offset=5, residual=r)
+    assert torch.equal(z, (r.float() + torch.where(kept, x.float() * (1.0 / (1.0 - p)), torch.zeros_like(x, dtype=torch.float32))).to(dt))   # one rounding
+    x2 = x.clone()
+    assert ops.dropout(x2, p, seed=77, offset=5, out=x2) is x2 and torch.equal(x2, y)
+    assert torch.equal(ops.dropout(x, 0.0, seed=1), x)
+    from setok_amd._lib import SetokHipError
+    with pytest.raises(SetokHipError):
+        ops.dropout(x, 1.0, seed=1)
+
+
+def _block_with_masks(sd, prefix, x, bounds, nheads, depth, masks):
+    """Block.forward in TRAINING mode on packed rows (segments = `bounds`), torch autograd, the dropout masks given: masks[i] multiplies the
+    attention projection of layer i, masks[depth] the Mlp activation, masks[depth + 1] the fc2 output (module.py:40-45,71-72,96-98)."""
+    n, C = x.shape
+    dh = C // nheads
+    g1, b1 = sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"]
+    for i in range(depth):
+        a = prefix + f"layers.{i}.1."
+        y = F.layer_norm(x, (C,), g1, b1, 1e-5)
+        qkv = F.linear(y, sd[a + "qkv.weight"], sd[a + "qkv.bias"])
+        outs = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            q, kk, v = qkv[lo:hi].reshape(hi - lo, 3, nheads, dh).permute(1, 2, 0, 3)
+            att = torch.softmax((q @ kk.transpose(-2, -1)) * (dh ** -0.5), dim=-1)
+            outs.append((att @ v).transpose(0, 1).reshape(hi - lo, C))
+        x = x + masks[i] * F.linear(torch.cat(outs, 0), sd[a + "proj.weight"], sd[a + "proj.bias"])
+    y = F.layer_norm(x, (C,), sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 1e-5)
+    u = masks[depth] * F.gelu(F.linear(y, sd[prefix + "mlp.fc1.weight"], sd[prefix + "mlp.fc1.bias"]))
+    return x + masks[depth + 1] * F.linear(u, sd[prefix + "mlp.fc2.weight"], sd[prefix + "mlp.fc2.bias"])
+
+
+def test_head_gradients_with_dropout_match_autograd(golden_dir):
+    """The training-mode step of the head (masks active at the three proj_drop sites of both Blocks) against torch autograd (fp64) through the same
+    arithmetic with the SAME masks (read back from setok_dropout): tokens and all 34 parameter gradients."""
+    sd, hidden, ups, _, thr, counts = _grad_case(golden_dir)
+    tok = _small_tok(sd)
+    p, seed = 0.2, 12345
+    tok.inner_encoder.proj_drop_p = tok.inter_encoder.proj_drop_p = p
+    tokens, ctx = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr, dropout_seed=seed)
+    assert tokens.counts == counts
+    ev, _ = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr)
+    assert _rel(tokens.packed, ev.packed) > 1e-2                                                 # the masks did something
+    grads = head_backward(tok, ctx, torch.cat(ups, 0).to(DEV))
+    # ---- the reference: same packed rows, same segments, same masks
+    hs = ctx["inner"]["x"][0].double().cpu()
+    seg = ctx["seg_offsets"].cpu().tolist()[: ctx["total"] + 1]
+    img = ctx["img_offsets"].cpu().tolist()
+    d_in, d_it = len(tok.inner_encoder._pack()["attn"]), len(tok.inter_encoder._pack()["attn"])
+    C, FF, rows, L = 64, 128, hs.shape[0], ctx["total"]
+
+    def factors(site0, depth, n):
+        widths = [C] * depth + [FF, C]
+        return [ops.dropout(torch.ones(n, w, device=DEV), p, seed, (site0 + i) * SITE_STRIDE).double().cpu() for i, w in enumerate(widths)]
+    m_in, m_it = factors(0, d_in, rows), factors(d_in + 2, d_it, L)
+    params = {n: v.double().clone().requires_grad_(True) for n, v in sd.items() if n.split(".")[0] in ("inner_encoder", "inter_encoder", "out")
+              and not (".layers." in n and n.split(".layers.")[1].split(".")[1] == "0")}
+    for n in [k for k in sd if ".layers." in k and k.split(".layers.")[1].split(".")[1] == "0"]:        # norm1 aliases (module.py:87-88)
+        params[n] = params[n.split(".layers.")[0] + ".norm1." + n.split(".")[-1]]
+    inner = _block_with_masks(params, "inner_encoder.", hs, seg, 2, d_in, m_in)
+    group = torch.stack([inner[lo:hi].mean(0) for lo, hi in zip(seg[:-1], seg[1:])], 0)
+    inter = _block_with_masks(params, "inter_encoder.", group, img[: 3], 2, d_it, m_it)
+    want = F.linear(inter, params["out.weight"], params["out.bias"])
+    assert _rel(tokens.packed, want) < 1e-5
+    (want * torch.cat(ups, 0).double()).sum().backward()
+    ref = {n: q.grad for n, q in params.items() if q.grad is not None and not (".layers." in n and n.split(".layers.")[1].split(".")[1] == "0")}
+    assert set(grads) == set(ref)
+    worst = {n: _rel(grads[n], ref[n]) for n in ref}
+    assert max(worst.values()) < 1e-4, {n: e for n, e in worst.items() if e >= 1e-4}
+    # same seed, same step; another seed, another step
+    t2, _ = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr, dropout_seed=seed)
+    t3, _ = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr, dropout_seed=seed + 1)
+    assert torch.equal(t2.packed, tokens.packed) and not torch.equal(t3.packed, tokens.packed)
+
+
+def test_trainer_dropout_policies(golden_dir):
+    """HeadTrainer(dropout=...): "train" draws new masks every step from (seed, step, rank) and repeats them for the same (seed, step); attn_drop > 0
+    raises; "error" refuses a module built with proj_drop > 0; "eval" is the unregularised forward."""
+    sd, hidden, ups, _, thr, _ = _grad_case(golden_dir)
+    tok = _small_tok(sd)
+    tok.inner_encoder.proj_drop_p = tok.inter_encoder.proj_drop_p = 0.2
+    with pytest.raises(NotImplementedError):
+        HeadTrainer(tok, dropout="error")
+    tr = HeadTrainer(tok, lr=1e-3, dropout="train", dropout_seed=9)
+    s0 = tr.step_seed()
+    a, ctx = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr, dropout_seed=tr.step_seed())
+    tr.backward(ctx, torch.cat(ups, 0).to(DEV)); tr.step()
+    assert tr.step_seed() != s0 and HeadTrainer(tok, dropout="train", dropout_seed=9).step_seed() == s0
+    ev, _ = head_forward_train(tok, hidden.to(DEV), 2, threshold=thr)
+    assert torch.isfinite(a.packed).all() and not torch.equal(a.packed, ev.packed)
+    tok.inner_encoder.attn_drop_p = 0.1
+    with pytest.raises(NotImplementedError):
+        HeadTrainer(tok, dropout="train")
+    with pytest.raises(NotImplementedError):
+        head_forward_train(tok, hidden.to(DEV), 2, threshold=thr, dropout_seed=1)
 
 
 def test_training_step_bf16_runs_and_reduces_loss():
