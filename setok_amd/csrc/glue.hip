@@ -3,31 +3,60 @@
 #include "common.h"
 
 // images (B,3,H,W) -> patches (B*g*g, Kpad), column = c*p*p + py*p + px, zero padded to Kpad.
-template <typename T>
-__global__ void patchify_kernel(const T* __restrict__ img, T* __restrict__ out, int B, int H, int W, int p, int Kpad) {
+// A thread owns ONE column of the patch matrix: its (c, py, px) and the image offset they mean are computed once; the workgroup then walks
+// over the patches (a wave-uniform row index: scalar arithmetic), so the per-element work is one add, one load, one store — the first
+// version decomposed a 64-bit flat index with six runtime divisions per element (177 us for 256 images of 224^2 against 45).
+// VW = 2: a thread owns two adjacent columns (even p: both in one image row, 4-byte aligned when W is even) — half the memory instructions.
+template <typename T, int VW>
+__global__ __launch_bounds__(1024) void patchify_kernel(const T* __restrict__ img, T* __restrict__ out, int B, int H, int W, int p, int Kpad) {
+    constexpr int MAXC = 4 / VW;                                   // column groups per thread: Kpad <= 4096 (patches up to 36 x 36 pixels)
     const int gh = H / p, gw = W / p, K = 3 * p * p;
-    const int64_t total = (int64_t)B * gh * gw * Kpad;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % Kpad);
-        const int64_t pr = i / Kpad;
-        float v = 0.f;
-        if (col < K) {
-            const int px = col % p, py = (col / p) % p, c = col / (p * p);
-            const int gx = (int)(pr % gw), gy = (int)((pr / gw) % gh), b = (int)(pr / ((int64_t)gw * gh));
-            v = Elem<T>::ld(img + (((int64_t)b * 3 + c) * H + gy * p + py) * W + gx * p + px);
+    int64_t off[MAXC]; bool live[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int col = (threadIdx.x + j * blockDim.x) * VW;
+        live[j] = col < K;
+        const int px = col % p, py = (col / p) % p, c = col / (p * p);
+        off[j] = live[j] ? ((int64_t)c * H + py) * W + px : 0;
+    }
+    const int npatch = B * gh * gw;
+    for (int pr = blockIdx.x; pr < npatch; pr += gridDim.x) {
+        const int gx = pr % gw, gy = (pr / gw) % gh, b = pr / (gw * gh);
+        const T* src = img + ((int64_t)b * 3 * H + gy * p) * W + gx * p;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            const int col = (threadIdx.x + j * blockDim.x) * VW;
+            if (col >= Kpad) continue;
+            T* dst = out + (int64_t)pr * Kpad + col;
+            if constexpr (VW == 2) {
+                typedef T pair_t __attribute__((ext_vector_type(2)));
+                pair_t v = {T(0.f), T(0.f)};
+                if (live[j]) v = *reinterpret_cast<const pair_t*>(src + off[j]);
+                *reinterpret_cast<pair_t*>(dst) = v;
+            } else {
+                Elem<T>::st(dst, live[j] ? Elem<T>::ld(src + off[j]) : 0.f);
+            }
         }
-        Elem<T>::st(out + i, v);
     }
 }
 
 extern "C" int setok_patchify(void* stream, int dtype, const void* images, void* patches, int B, int H, int W, int p, int Kpad) {
     SETOK_CHECK_ARG(images && patches, "setok_patchify: null operand");
     SETOK_CHECK_ARG(B > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= 3 * p * p, "setok_patchify: bad shape");
-    const int64_t total = (int64_t)B * (H / p) * (W / p) * Kpad;
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    SETOK_CHECK_ARG(Kpad <= 4096, "setok_patchify: Kpad=%d above 4096 (a patch of more than 36 x 36 pixels)", Kpad);
+    const int npatch = B * (H / p) * (W / p);
+    const bool pairs = p % 2 == 0 && W % 2 == 0 && Kpad % 2 == 0;     // (px, px + 1) share an image row and are 4-byte aligned (8-byte in fp32)
+    const int groups = pairs ? Kpad / 2 : Kpad;
+    const int threads = groups >= 1024 ? 1024 : ((groups + 63) & ~63);
+    const int grid = npatch < 256 * 16 ? npatch : 256 * 16;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SETOK_BF16) patchify_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)images, (bf16*)patches, B, H, W, p, Kpad);
-    else if (dtype == SETOK_F32) patchify_kernel<float><<<grid, 256, 0, s>>>((const float*)images, (float*)patches, B, H, W, p, Kpad);
+    if (dtype == SETOK_BF16) {
+        if (pairs) patchify_kernel<bf16, 2><<<grid, threads, 0, s>>>((const bf16*)images, (bf16*)patches, B, H, W, p, Kpad);
+        else patchify_kernel<bf16, 1><<<grid, threads, 0, s>>>((const bf16*)images, (bf16*)patches, B, H, W, p, Kpad);
+    } else if (dtype == SETOK_F32) {
+        if (pairs) patchify_kernel<float, 2><<<grid, threads, 0, s>>>((const float*)images, (float*)patches, B, H, W, p, Kpad);
+        else patchify_kernel<float, 1><<<grid, threads, 0, s>>>((const float*)images, (float*)patches, B, H, W, p, Kpad);
+    }
     else return setok_fail(SETOK_EINVAL, "setok_patchify: bad dtype %d", dtype);
     SETOK_CHECK_LAUNCH("setok_patchify");
     return SETOK_OK;

@@ -229,13 +229,13 @@ def test_attention_ragged_head_dim_512_bf16(lens):
 # glue
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_patchify_matches_conv(dt):
-    B, p, g = 2, 14, 4
+@pytest.mark.parametrize("B,p,g", [(2, 14, 4), (3, 16, 14), (1, 32, 7), (5, 2, 3), (2, 7, 5), (1, 3, 2)])
+def test_patchify_matches_conv(dt, B, p, g):
     img = _rand(B, 3, p * g, p * g, seed=10).to(dt)
     w = _rand(8, 3, p, p, seed=11).to(dt)
     kpad = ops.round_up(3 * p * p, 64)
     pat = ops.patchify(img.to(DEV), p, kpad).cpu()
-    assert pat.shape == (B * g * g, kpad) and float(pat[:, 3 * p * p:].abs().max()) == 0.0
+    assert pat.shape == (B * g * g, kpad) and (kpad == 3 * p * p or float(pat[:, 3 * p * p:].abs().max()) == 0.0)
     ref = F.conv2d(img.double(), w.double(), stride=p).flatten(2).transpose(1, 2).reshape(B * g * g, 8)
     got = pat[:, :3 * p * p].double() @ w.double().reshape(8, -1).t()
     assert _rel_err(got, ref) < 1e-12
