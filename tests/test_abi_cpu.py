@@ -57,3 +57,12 @@ def test_no_fallback_when_library_missing(lib, monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libsetok_hip.so")
     with pytest.raises(lib.SetokHipError):
         lib.load()
+
+
+def test_driver_build_entry_point():
+    """`__graft_entry__.build()` — what the driver runs as its build check: make + import + ABI version against the header."""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").build()
