@@ -474,6 +474,51 @@ def test_cluster_fused_bf16_every_branch(N, C, m, k, mcn, thr, with_noise, with_
     print(f"fused vs multi-kernel: {n_same}/{B} images with identical integers")
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_cluster_fused_random_shapes_against_the_oracle(seed):
+    """Seeded random (N, C, k, min_cluster_num, threshold) with the data the shortcuts of the fused kernel care about — exact duplicate tokens
+    (distances of exactly 0 beside the self-distance: no common prefix for the radix select), N < 256 (columns padded with +inf), k = 2 and
+    k = N — against the fp64 margin analysis of the oracle (the contract of the bf16 mode: decisions equal wherever 64 ulps of d^2 cannot flip
+    them, scores inside the envelope), and against the multi-kernel form of the same call (equal selections).
+    Left out on purpose: k = 1 and constant features.  With k = 1 every density is exp(-d_ii^2); the kernels' self-distance is exactly 0 (the
+    norms ARE the Gram diagonal) while torch.cdist's matmul form leaves rounding noise there (tokenizer.py:82), so the reference's own result is
+    decided by that noise; with identical tokens every score ties at 0 and torch.topk's order among ties is unspecified."""
+    import random
+    rng = random.Random(1000 + seed)
+    N = rng.choice([256, 256, 200, 129, 64, 33, 16, rng.randint(2, 256)])
+    C = 64 * rng.randint(1, 8)
+    k = rng.choice([2, N, min(N, 64), rng.randint(2, N)])
+    mcn = rng.randint(1, min(N, 64))
+    thr = rng.choice([0.5, 0.1, 1e9])
+    m = rng.randint(2, 12)
+    gx = torch.Generator().manual_seed(500 + seed)                # m planted centres, any N (O.planted_features wants a square grid)
+    x = (torch.randn(min(N, m), C, generator=gx) * 2.0)[torch.randint(0, min(N, m), (N,), generator=gx)] + 0.05 * torch.randn(N, C, generator=gx)
+    dups = seed % 3 == 0
+    if dups:                                             # exact duplicates
+        for _ in range(rng.randint(1, 6)):
+            a, b = rng.randrange(N), rng.randrange(N)
+            x[a] = x[b]
+    x = x.bfloat16()
+    g = torch.Generator().manual_seed(seed)
+    noise = torch.rand(N, generator=g) if seed % 2 else None
+    nz = None if noise is None else noise[None].to(DEV)
+    idx, score, index_down, counts = ops.cluster_dpc_knn(x.to(DEV), 1, N, k, thr, mcn, nz, None)
+    os.environ["SETOK_CLUSTER_FUSED"] = "0"
+    try:
+        idx_m, score_m, down_m, counts_m = ops.cluster_dpc_knn(x.to(DEV), 1, N, k, thr, mcn, nz, None)
+    finally:
+        del os.environ["SETOK_CLUSTER_FUSED"]
+    L = int(counts[0])
+    assert L == int(counts_m[0]) and torch.equal(index_down[0, :L], down_m[0, :L]) and torch.equal(idx, idx_m)       # the two forms select alike
+    r = O.cluster_dpc_knn(x.float(), k, thr, mcn, None, noise)
+    wide = k == N or dups                                # whole-row means / exact ties: rounding of exp and of the mean decides, beyond a d^2 perturbation
+    sens = O.cluster_sensitivity(x.float(), k, thr, mcn, None, noise, ulps=4096.0 if wide else 64.0)
+    assert 1 <= L <= N and int(idx[0].max()) < L and int(idx[0].min()) >= 0 and bool(torch.isfinite(score).all())
+    O.check_cluster_parity(index_down[0, :L].cpu(), idx[0].cpu(), r.index_down, r.idx_cluster, sens)
+    if not wide:
+        O.check_score(score[0].cpu(), sens)
+
+
 def test_cluster_fused_needs_no_workspace_and_is_deterministic():
     from setok_amd import _lib
     import ctypes
