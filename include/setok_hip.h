@@ -42,9 +42,11 @@ const char* setok_last_error(void);
 int setok_device_info(char* name_host, int name_cap, int* cu_count_host);
 
 /* Launch profiler (measurement aid, off by default; process-wide): between start and stop every setok_linear / setok_linear_ln /
- * setok_cluster_dpc_knn call is bracketed by HIP events on its stream.  stop waits for them and returns the number of records written:
+ * setok_cluster_dpc_knn call is timed by a pair of HIP events on its stream — attached to the call's first and last kernel dispatch
+ * (hipExtLaunchKernelGGL: the dispatches' own start / end timestamps, no marker packets) where the call launches the LDS-DMA GEMM kernels or
+ * the single-launch clustering, recorded as markers around the call otherwise.  stop waits for them and returns the number of records written:
  * kind 0 = bf16 GEMM, 1 = fp32 GEMM (work = FLOPs), 2 = clustering (work = Gram FLOPs); cls = act | residual << 2 | folded LayerNorm << 3;
- * bytes = algorithmic bytes of the call; ms = event duration. */
+ * bytes = algorithmic bytes of the call; ms = event duration.  Call start / stop while no other library call is in flight. */
 int setok_profile_start(void);
 int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* ms, int cap);
 
