@@ -145,9 +145,13 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         const bf16* Wb_ = F32B ? g.W + (int64_t)b * g.sW : g.W;
         a_base = reinterpret_cast<const char*>(Ab_ + (int64_t)m0 * g.lda);
         b_base = reinterpret_cast<const char*>(Wb_ + (int64_t)n0 * g.K);
+        // rows / slots from an opaque copy of the thread id: computed outside the tile loop these eight values live across the main loop and, in the
+        // kernel with a residual, came back from scratch one load + vmcnt(0) at a time at every tile boundary
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int p = i * 512 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
+            const int p = i * 512 + tid_e, row = p >> 3, kc = (p & 7) ^ swz(row);
             a_off[i] = (unsigned)min(row, g.M - 1 - m0) * (unsigned)(g.lda * 2) + kc * 16;       // < 256 rows x lda x 2 bytes
             b_off[i] = (unsigned)min(row, g.N - 1 - n0) * (unsigned)(g.K * 2) + kc * 16;
         }
