@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 4
+#define SETOK_ABI_VERSION 5
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -268,9 +268,19 @@ int setok_splice_plan(void* stream, const int64_t* input_ids, const uint8_t* att
                       int32_t* src, int64_t* new_labels, uint8_t* new_mask, int64_t* new_position_ids);
 
 /* Step 3.  out[r, :] = embed_table[src[r]] | image_tokens[-(src[r] + 1)] | 0, r < rows = B * max_len: embed_tokens (:266,284)
- * fused with the concatenations and the zero padding (:296-303, 324-333).  D * sizeof(dtype) must be a multiple of 16. */
+ * fused with the concatenations and the zero padding (:296-303, 324-333).  D * sizeof(dtype) must be a multiple of 16.
+ * A src the operands cannot serve (>= vocab; an image-token row >= image_token_rows or with image_tokens == NULL, e.g. an
+ * IMAGE_TOKEN_INDEX in a text-only call) is never turned into an address: the row is zero-filled and, with `status` (int32[2], optional,
+ * device), status[0] = 1 and status[1] = the first such row — where the reference's embed_tokens raises IndexError (:273). */
 int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* embed_table, int vocab, const void* image_tokens,
-                      void* out, int64_t rows, int D);
+                      int64_t image_token_rows, void* out, int64_t rows, int D, int32_t* status);
+
+/* Backward of step 3 (the reference gets it from autograd: stage 2 trains mm_in_projector THROUGH the splice, scripts/pretrain_mm_proj.sh:40,
+ * setokim_arch.py:290-293): d_image_tokens[-(src[r] + 1)] = d_out[r] (rows no output position consumed — truncation — are zero);
+ * d_embed (fp32 (vocab, D), optional, ACCUMULATED into: the caller zeroes it) += d_out[r] at src[r] >= 0 — hardware fp32 atomics, the
+ * summation order over a repeated token id is not fixed.  Either output may be NULL. */
+int setok_splice_rows_bwd(void* stream, int dtype, const int32_t* src, const void* d_out, int64_t rows, int D,
+                          void* d_image_tokens, int64_t image_token_rows, float* d_embed, int vocab);
 
 /* ---- training step of the trainable head --------------------------------------------------------------
  * The reference trains through torch autograd (src/train/setok_trainer.py / train_setokim.py drive `loss.backward()`); the tower is

@@ -327,6 +327,65 @@ def rac_head_grads(tok, feats_list, upstream_list, k=None, threshold=None, noise
     return grads, counts
 
 
+# ----------------------------------------------------------------------------------------------
+# Stage 2 (scripts/pretrain_mm_proj.sh:40, train_setokim.py:336-339): mm_in_projector is trained THROUGH the splice.  The reference's own
+# `build_vision_projector` module (multimodal_projector/builder.py:33-59, loaded by file path) feeds the reference's own
+# prepare_inputs_labels_for_multimodal (as above, but with gradients enabled), and torch autograd carries a downstream loss back.
+# ----------------------------------------------------------------------------------------------
+def load_reference_projector_builder():
+    name = "rac_projector_builder"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, "src", "model", "multimodal_projector", "builder.py"))
+    mod = importlib.util.module_from_spec(spec); sys.modules[name] = mod; spec.loader.exec_module(mod)
+    return mod
+
+
+def rac_stage2_grads(projector, tokens_list, input_ids, position_ids, attention_mask, labels, embed_weight, w_down,
+                     max_length=None, padding_side="right", train_embed=False):
+    """loss = downstream(prepare_inputs_labels_for_multimodal(..., encode_images = projector(tokens_i))).  Returns (loss, embeds, new_labels,
+    {projector parameter gradients}, [d loss / d tokens_i], d loss / d embed_weight or None) — all by the reference's modules under torch autograd."""
+    arch = load_reference_arch()
+    emb = torch.nn.Embedding.from_pretrained(embed_weight.clone(), freeze=not train_embed)
+
+    class _Model:
+        embed_tokens = emb
+
+    class _Cfg:
+        pass
+    cfg = _Cfg()
+    if max_length is not None:
+        cfg.tokenizer_model_max_length = max_length
+    cfg.tokenizer_padding_side = padding_side
+    toks = [t.detach().clone().requires_grad_(True) for t in tokens_list]
+    for p in projector.parameters():
+        p.requires_grad_(True)
+    projector.zero_grad(set_to_none=True)
+
+    class Host(arch.SetokimMetaForCausalLM):
+        config = cfg
+        device = embed_weight.device
+
+        def get_model(self):
+            return _Model()
+
+        def get_vision_tower(self):
+            return object()
+
+        def encode_images(self, images):                        # setokim_arch.py:206-211 with the tokenizer's output handed in
+            return [projector(t) for t in toks]
+
+    images = torch.zeros(len(toks), 3, 2, 2)
+    _, pos, am, _, embeds, new_labels = Host().prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, None, labels, images)
+    from setok_oracle import stage2_downstream
+    loss = stage2_downstream(embeds, new_labels, w_down)
+    loss.backward()
+    pg = {n: p.grad.detach().clone() for n, p in projector.named_parameters()}
+    tg = [t.grad.detach().clone() if t.grad is not None else torch.zeros_like(t) for t in toks]
+    eg = emb.weight.grad.detach().clone() if train_embed else None
+    return loss.detach(), embeds.detach(), new_labels, pg, tg, eg
+
+
 def rac_lm_loss(logits, new_labels, attention_mask):
     """The reference's own loss statements (src/model/language_model/setokim_llama.py:145-160, inside `SetokimLlamaForCausalLM.forward`,
     which cannot be instantiated here) executed as they stand: the lines are read from the reference file at call time, dedented and run

@@ -688,6 +688,17 @@ def splice_inputs(seed, B, T, V, D, max_imgs=3, pad=True):
     return ids, am, labels, feats, W
 
 
+def stage2_downstream(embeds, new_labels, w_down):
+    """The small stand-in for the LLM behind inputs_embeds in the stage-2 gradient tests (test infrastructure, shared by the golden generator —
+    where it sits behind the REFERENCE's projector and splice — and the GPU test): a tanh, a vocabulary projection, the shifted cross entropy of
+    setokim_llama.py:145-160's shape and a small log-partition term that gives EVERY position (image rows included, whose next-token labels
+    are mostly IGNORE_INDEX) a gradient."""
+    logits = torch.tanh(embeds.float()) @ w_down.float().t()
+    V = logits.shape[-1]
+    ce = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, V), new_labels[:, 1:].reshape(-1), ignore_index=-100)
+    return ce + 0.05 * torch.logsumexp(logits, dim=-1).mean()
+
+
 # ----------------------------------------------------------------------------------------------
 # §8(f) last row — the LLM prefill of cfg 5: SetokimLlamaForCausalLM.forward (setokim_llama.py:94-143) = the splice above, then
 # `self.model(inputs_embeds=..., attention_mask=..., position_ids=...)` and `self.lm_head` (:130-143).  `self.model` is HuggingFace

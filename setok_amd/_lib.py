@@ -70,7 +70,8 @@ SIGNATURES = {
     "setok_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
     "setok_attention_causal": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f],
     "setok_lm_loss": [_vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
-    "setok_splice_rows": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _i],
+    "setok_splice_rows": [_vp, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp],
+    "setok_splice_rows_bwd": [_vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i],
 }
 
 _lib = None

@@ -10,8 +10,7 @@ from dataclasses import asdict, is_dataclass
 import torch
 import torch.nn as nn
 
-from . import ops
-from ._packcache import f32_of
+from . import autograd
 from .detokenizer import SetokDeTokenizer
 from .tokenizer import SetokTokenizer
 
@@ -62,31 +61,28 @@ class IdentityMap(nn.Module):                         # multimodal_projector/bui
 
 class VisionProjector(nn.Sequential):
     """nn.Sequential-compatible parameter tree (keys `0.weight`, `2.weight`, ...) whose forward runs on
-    the HIP library: Linear+GELU pairs are one GEMM with a fused exact-erf GELU epilogue."""
+    the HIP library: Linear+GELU pairs are one GEMM with a fused exact-erf GELU epilogue.
 
-    @torch.no_grad()
+    Differentiable like the reference's nn.Sequential (stage 2 trains exactly this module through the LLM loss,
+    scripts/pretrain_mm_proj.sh:40): with gradients enabled and a parameter or the input requiring one, the same calls run inside
+    `autograd.ProjectorFn` (forward bits unchanged) and `loss.backward()` fills `.grad` of the parameters and of the tokens."""
+
     def forward(self, x):
         if hasattr(x, "map") and hasattr(x, "packed"):            # RaggedTokens: project all tokens at once
             return x.map(self.forward)
         shape = x.shape
-        h = x.reshape(-1, shape[-1]).contiguous()
-        mods = list(self)
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Linear):
-                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU)
-                h = ops.linear(h, m.weight.detach().contiguous(), f32_of(m, "bias", m.bias), act=ops.ACT_GELU_ERF if fuse else ops.ACT_NONE)
-                i += 2 if fuse else 1
-            elif isinstance(m, nn.LayerNorm):
-                h = ops.layernorm(h, f32_of(m, "weight", m.weight), f32_of(m, "bias", m.bias), m.eps)
-                i += 1
-            elif isinstance(m, nn.GELU):
-                h = ops.activation(h, ops.ACT_GELU_ERF)
-                i += 1
-            else:
-                raise TypeError(f"unsupported projector module {type(m).__name__}")
+        h = x.reshape(-1, shape[-1])
+        plan, tensors = autograd.projector_plan(list(self))
+        if autograd.grad_needed(h, *tensors):
+            h = autograd.ProjectorFn.apply(h, plan, self, *tensors)
+        else:
+            with torch.no_grad():
+                h = autograd.ProjectorFn.forward(_NoCtx(), h.detach(), plan, self, *tensors)
         return h.reshape(*shape[:-1], h.shape[-1])
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when no graph is recorded: the forward is one code path either way."""
 
 
 def build_vision_projector(projector_type="linear", mm_hidden_size=4096, hidden_size=3078, delay_load=False, **kwargs):
@@ -112,14 +108,19 @@ def build_vision_projector(projector_type="linear", mm_hidden_size=4096, hidden_
 
 
 class LinearProjector(nn.Linear):
-    """`projector_type == 'linear'`: a bare nn.Linear in the reference (keys `weight`, `bias`)."""
+    """`projector_type == 'linear'`: a bare nn.Linear in the reference (keys `weight`, `bias`).  Differentiable like VisionProjector."""
 
-    @torch.no_grad()
     def forward(self, x):
         if hasattr(x, "map") and hasattr(x, "packed"):
             return x.map(self.forward)
         shape = x.shape
-        h = ops.linear(x.reshape(-1, shape[-1]).contiguous(), self.weight.detach().contiguous(), f32_of(self, "bias", self.bias))
+        h = x.reshape(-1, shape[-1])
+        plan, tensors = (("linear", False, self.bias is not None),), [self.weight] + ([self.bias] if self.bias is not None else [])
+        if autograd.grad_needed(h, *tensors):
+            h = autograd.ProjectorFn.apply(h, plan, self, *tensors)
+        else:
+            with torch.no_grad():
+                h = autograd.ProjectorFn.forward(_NoCtx(), h.detach(), plan, self, *tensors)
         return h.reshape(*shape[:-1], h.shape[-1])
 
 

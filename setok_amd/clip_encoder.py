@@ -18,7 +18,7 @@ from typing import Any, Dict, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd, ops
 from ._packcache import PackCacheMixin
 
 _VIT_DEFAULTS = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
@@ -168,8 +168,9 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
         GEMM operand, fp32 biases / LayerNorm affine."""
         vt = self.vision_tower
         # one weight per encoder layer + the embeddings: a state-dict load rewrites all of them (and fires the post-hook anyway)
-        key = (vt.dtype, str(vt.device), os.environ.get("SETOK_LN_FOLD", "1"), self._versions([l.mlp.fc1.weight for l in vt.encoder.layers]
-                                                       + [vt.embeddings.patch_embedding.weight, vt.pre_layrnorm.weight]))
+        # every parameter's counter (a few hundred integer reads per forward): an in-place update of ANY of them — a LoRA merge into q_proj / v_proj,
+        # an edited layer_norm1 — must rebuild the fused q|k|v and folded-LayerNorm copies
+        key = (vt.dtype, str(vt.device), os.environ.get("SETOK_LN_FOLD", "1"), self._versions(vt.parameters()))
         if self._packed.get("key") == key:
             return self._packed
         cfg, dt = vt.cfg, vt.dtype
@@ -210,11 +211,17 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
             raise IndexError(f"select_layer {self.select_layer} out of range")
         return idx
 
-    @torch.no_grad()
     def hidden_rows(self, images: torch.Tensor) -> torch.Tensor:
-        """(B*(N+1), C) rows of hidden_states[select_layer] (class token first in each image)."""
+        """(B*(N+1), C) rows of hidden_states[select_layer] (class token first in each image).  Inference only, like the reference's
+        `@torch.no_grad()` forward (clip_encoder.py:50) — but a tower whose parameters were unfrozen (`unfreeze_mm_vision_tower`, or a manual
+        `requires_grad_(True)`) is refused loudly rather than silently not trained."""
         if not self.is_loaded:
             raise RuntimeError("vision tower not loaded: call load_model() first")
+        autograd.refuse_grad("CLIPVisionTower (the ViT tower has no backward pass on the HIP path)", self.vision_tower.parameters())
+        with torch.no_grad():
+            return self._hidden_rows(images)
+
+    def _hidden_rows(self, images: torch.Tensor) -> torch.Tensor:
         cfg = self.config
         if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != cfg.image_size or images.shape[3] != cfg.image_size:
             raise ValueError(f"Input image size ({images.shape[-2]}*{images.shape[-1]}) doesn't match model "

@@ -150,20 +150,57 @@ __global__ __launch_bounds__(256) void splice_plan_kernel(const int64_t* __restr
     }
 }
 
-// One wave per output row, 16-byte pieces.
+__global__ void splice_status_init_kernel(int32_t* status) { status[0] = 0; status[1] = INT32_MAX; }
+
+// One wave per output row, 16-byte pieces.  An id the tables cannot serve (>= vocab, or an image-token row when no image tokens were
+// handed over: e.g. an IMAGE_TOKEN_INDEX in a text-only call) never becomes an address: the row is zero-filled and, when `status` is given,
+// status[0] = 1 and status[1] = the smallest such row (the reference's embed_tokens raises IndexError there, setokim_arch.py:273).
 __global__ __launch_bounds__(256) void splice_rows_kernel(const int32_t* __restrict__ src, const char* __restrict__ embed,
                                                           const char* __restrict__ feats, char* __restrict__ out, int64_t rows,
-                                                          int row_bytes, int vocab) {
+                                                          int row_bytes, int vocab, int64_t feat_rows, int32_t* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
         const int s = src[r];
         const char* from = nullptr;
-        if (s >= 0) from = embed + (int64_t)min(s, vocab - 1) * row_bytes;
-        else if (s != SRC_PAD) from = feats + (int64_t)(-(s + 1)) * row_bytes;
+        bool bad = false;
+        if (s >= 0) { if (s < vocab) from = embed + (int64_t)s * row_bytes; else bad = true; }
+        else if (s != SRC_PAD) {
+            const int64_t fr = -((int64_t)s + 1);
+            if (feats && fr < feat_rows) from = feats + fr * row_bytes; else bad = true;
+        }
+        if (bad && status && lane == 0) { atomicExch(&status[0], 1); atomicMin(&status[1], (int)min(r, (int64_t)INT32_MAX)); }
         char* to = out + r * row_bytes;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         for (int o = lane * 16; o < row_bytes; o += 64 * 16)
             *reinterpret_cast<f32x4*>(to + o) = from ? *reinterpret_cast<const f32x4*>(from + o) : zero;
+    }
+}
+
+// Backward of the row copies: d image_tokens[-(src[r] + 1)] = d out[r] (an image-token row is consumed by at most one output position,
+// setokim_arch.py:290-293: plain copies, no conflicts; rows the truncation dropped keep the zeros the caller's memset left), and — when
+// the embedding table is trained — d embed[src[r]] += d out[r] in fp32 (token ids repeat: hardware fp32 atomics, so the summation order of
+// a repeated id's rows is not fixed; torch's own embedding backward makes the same trade).
+template <typename T>
+__global__ __launch_bounds__(256) void splice_rows_bwd_kernel(const int32_t* __restrict__ src, const T* __restrict__ dout, T* __restrict__ dfeats,
+                                                              float* __restrict__ dembed, int64_t rows, int D, int vocab, int64_t feat_rows) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int s = src[r];
+        const T* from = dout + r * D;
+        if (s >= 0) {
+            if (dembed && s < vocab) {
+                float* to = dembed + (int64_t)s * D;
+                for (int c = lane; c < D; c += 64) unsafeAtomicAdd(to + c, (float)from[c]);
+            }
+        } else if (s != SRC_PAD && dfeats) {
+            const int64_t fr = -((int64_t)s + 1);
+            if (fr < feat_rows) {
+                T* to = dfeats + fr * D;
+                constexpr int V = 16 / sizeof(T);
+                for (int c = lane * V; c < D; c += 64 * V)
+                    *reinterpret_cast<f32x4*>(to + c) = *reinterpret_cast<const f32x4*>(from + c);
+            }
+        }
     }
 }
 
@@ -197,16 +234,38 @@ extern "C" int setok_splice_plan(void* stream, const int64_t* input_ids, const u
 }
 
 extern "C" int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* embed_table, int vocab,
-                                 const void* image_tokens, void* out, int64_t rows, int D) {
+                                 const void* image_tokens, int64_t image_token_rows, void* out, int64_t rows, int D, int32_t* status) {
     SETOK_CHECK_ARG(src && embed_table && out, "setok_splice_rows: null operand");
     SETOK_CHECK_ARG(dtype == SETOK_BF16 || dtype == SETOK_F32, "setok_splice_rows: bad dtype %d", dtype);
     const int row_bytes = D * (dtype == SETOK_BF16 ? 2 : 4);
-    SETOK_CHECK_ARG(rows >= 0 && D > 0 && row_bytes % 16 == 0 && vocab > 0, "setok_splice_rows: bad shape rows=%lld D=%d", (long long)rows, D);
+    SETOK_CHECK_ARG(rows >= 0 && D > 0 && row_bytes % 16 == 0 && vocab > 0 && image_token_rows >= 0, "setok_splice_rows: bad shape rows=%lld D=%d", (long long)rows, D);
+    hipStream_t s = (hipStream_t)stream;
+    if (status) splice_status_init_kernel<<<1, 1, 0, s>>>(status);
     if (rows == 0) return SETOK_OK;
     const int64_t want = (rows + 3) / 4;
     const int grid = (int)(want < 65536 * 4 ? want : 65536 * 4);
-    splice_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, (const char*)embed_table, (const char*)image_tokens, (char*)out, rows,
-                                                             row_bytes, vocab);
+    splice_rows_kernel<<<grid, 256, 0, s>>>(src, (const char*)embed_table, (const char*)image_tokens, (char*)out, rows, row_bytes, vocab,
+                                            image_tokens ? image_token_rows : 0, status);
     SETOK_CHECK_LAUNCH("setok_splice_rows");
+    return SETOK_OK;
+}
+
+extern "C" int setok_splice_rows_bwd(void* stream, int dtype, const int32_t* src, const void* d_out, int64_t rows, int D,
+                                     void* d_image_tokens, int64_t image_token_rows, float* d_embed, int vocab) {
+    SETOK_CHECK_ARG(src && d_out, "setok_splice_rows_bwd: null operand");
+    SETOK_CHECK_ARG(dtype == SETOK_BF16 || dtype == SETOK_F32, "setok_splice_rows_bwd: bad dtype %d", dtype);
+    const int es = dtype == SETOK_BF16 ? 2 : 4;
+    SETOK_CHECK_ARG(rows >= 0 && D > 0 && (D * es) % 16 == 0 && image_token_rows >= 0 && (!d_embed || vocab > 0), "setok_splice_rows_bwd: bad shape rows=%lld D=%d", (long long)rows, D);
+    hipStream_t s = (hipStream_t)stream;
+    if (d_image_tokens && image_token_rows > 0)
+        SETOK_CHECK_ARG(hipMemsetAsync(d_image_tokens, 0, (size_t)image_token_rows * D * es, s) == hipSuccess, "setok_splice_rows_bwd: memset failed");
+    if (rows == 0 || (!d_image_tokens && !d_embed)) return SETOK_OK;
+    const int64_t want = (rows + 3) / 4;
+    const int grid = (int)(want < 65536 * 4 ? want : 65536 * 4);
+    if (dtype == SETOK_BF16)
+        splice_rows_bwd_kernel<bf16><<<grid, 256, 0, s>>>(src, (const bf16*)d_out, (bf16*)d_image_tokens, d_embed, rows, D, vocab, image_token_rows);
+    else
+        splice_rows_bwd_kernel<float><<<grid, 256, 0, s>>>(src, (const float*)d_out, (float*)d_image_tokens, d_embed, rows, D, vocab, image_token_rows);
+    SETOK_CHECK_LAUNCH("setok_splice_rows_bwd");
     return SETOK_OK;
 }

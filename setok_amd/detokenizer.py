@@ -330,8 +330,14 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
             ops.linear(u, *b["fc2"], residual=h, out=h)
         return ops.layernorm(h, *pk["dec_ln"][:2], pk["dec_ln"][2], out=y)
 
-    @torch.no_grad()
     def forward(self, x, attention_masks: Optional[torch.Tensor] = None, return_stages: bool = False):
+        """Inference arithmetic (no autograd graph): refused loudly when gradients are enabled and a parameter or the tokens require one."""
+        from . import autograd
+        autograd.refuse_grad("SetokDeTokenizer.forward", [getattr(x, "packed", x) if not isinstance(x, (list, tuple)) else None, *(x if isinstance(x, (list, tuple)) else ()), *self.parameters()])
+        with torch.no_grad():
+            return self._forward(x, attention_masks, return_stages)
+
+    def _forward(self, x, attention_masks: Optional[torch.Tensor] = None, return_stages: bool = False):
         """x: RaggedTokens (the tokenizer's output), a list of (L_i, D) tensors, or padded (B, L, D) with
         `attention_masks` (B, L) (1 = token, 0 = padding; None = all tokens).  Returns (B, Q, decoder_embed_dim)."""
         if isinstance(x, (list, tuple)):

@@ -20,7 +20,7 @@ from typing import Any, Dict, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd, ops
 from ._packcache import PackCacheMixin
 from .arch import SetokimVisionMixin, config_get
 
@@ -76,7 +76,7 @@ class LlamaModel(PackCacheMixin, nn.Module):
 
     def _pack(self):
         w = self.norm.weight
-        key = (w.dtype, str(w.device), self._versions([w] + [l.mlp.down_proj.weight for l in self.layers]))
+        key = (w.dtype, str(w.device), self._versions(self.parameters()))      # every tensor: a LoRA merge into q_proj / v_proj alone must rebuild the fused copies
         if self._packed.get("key") == key:
             return self._packed
         f32 = lambda t: t.detach().float().contiguous()
@@ -91,10 +91,15 @@ class LlamaModel(PackCacheMixin, nn.Module):
         self._packed = dict(key=key, layers=layers, norm=f32(self.norm.weight))
         return self._packed
 
-    @torch.no_grad()
     def forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None):
         """inputs_embeds (B, T, D); attention_mask (B, T), 1 = token (None = all); position_ids (B, T) (None = 0..T-1).
-        Returns the hidden states after the final norm, (B, T, D)."""
+        Returns the hidden states after the final norm, (B, T, D).  A prefill: inference arithmetic, no autograd graph (refused loudly when one
+        would be needed — training the LLM is the reference's HF-Trainer side, SURVEY.md §2 "OUT")."""
+        autograd.refuse_grad("LlamaModel.forward (the prefill has no backward pass on the HIP path)", [inputs_embeds, *self.parameters()])
+        with torch.no_grad():
+            return self._forward(inputs_embeds, attention_mask, position_ids)
+
+    def _forward(self, inputs_embeds, attention_mask=None, position_ids=None):
         B, T, D = inputs_embeds.shape
         pk = self._pack()
         H, dh = self.num_heads, self.head_dim
@@ -136,9 +141,15 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
     def get_model(self):
         return self.model
 
-    @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, labels=None, comp_images=None,
                 last_token_only: bool = False, return_loss: bool = False):
+        autograd.refuse_grad("SetokimLlamaPrefill.forward (inference: encode -> splice -> prefill -> logits)",
+                             [inputs_embeds, *self.parameters()])
+        with torch.no_grad():
+            return self._forward(input_ids, attention_mask, position_ids, inputs_embeds, labels, comp_images, last_token_only, return_loss)
+
+    def _forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, labels=None, comp_images=None,
+                 last_token_only: bool = False, return_loss: bool = False):
         """Returns (logits, new_labels, attention_mask): logits (B, T', vocab) — or (B, vocab) for every sequence's last token with
         `last_token_only` (what a generation step after the prefill needs) — on the spliced sequence of length T'.  With `return_loss`
         (and labels) a fourth element is the language-model loss of setokim_llama.py:145-160 (shifted cross entropy over the positions whose
@@ -149,8 +160,16 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
             _, position_ids, attention_mask, _, inputs_embeds, new_labels = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, None, labels, comp_images)
             if inputs_embeds is None:                                              # no images: plain text
+                # text only: embed_tokens(input_ids).  An id the table cannot serve — an IMAGE_TOKEN_INDEX although no images came, a leaked
+                # TARGET_TOKEN_INDEX, an id >= vocab — raises the reference's IndexError (torch's embedding) instead of becoming an address
                 w_e = self.model.embed_tokens.weight.detach().contiguous()
-                inputs_embeds = ops.splice_rows(input_ids.to(device=w_e.device, dtype=torch.int32).contiguous(), w_e, None)
+                status = torch.empty(2, dtype=torch.int32, device=w_e.device)
+                inputs_embeds = ops.splice_rows(input_ids.to(device=w_e.device, dtype=torch.int32).contiguous(), w_e, None, status)
+                st = status.cpu()
+                if int(st[0]) != 0:
+                    b, t = divmod(int(st[1]), input_ids.shape[1])
+                    raise IndexError(f"index out of range in self: input_ids[{b}, {t}] = {int(input_ids[b, t])} is not a row of the "
+                                     f"{w_e.shape[0]}-row embedding table (and no images were passed for image placeholders)")
         hidden = self.model(inputs_embeds, attention_mask, position_ids)           # setokim_llama.py:130-140
         B, T, D = hidden.shape
         w = self.lm_head.weight.detach().contiguous()

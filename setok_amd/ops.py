@@ -308,15 +308,31 @@ def splice_plan(input_ids: Tensor, attention_mask: Optional[Tensor], labels: Opt
     return src, new_labels, new_mask, new_pos
 
 
-def splice_rows(src: Tensor, embed_table: Tensor, image_tokens: Optional[Tensor]) -> Tensor:
+def splice_rows(src: Tensor, embed_table: Tensor, image_tokens: Optional[Tensor], status: Optional[Tensor] = None) -> Tensor:
+    """status: optional int32[2] device tensor — [0] = 1 / [1] = first row whose src neither table can serve (such rows are zero-filled)."""
     B, max_len = src.shape
     V, D = embed_table.shape
     out = torch.empty((B, max_len, D), dtype=embed_table.dtype, device=embed_table.device)
+    n_img_rows = 0
     if image_tokens is not None:
         assert image_tokens.dtype == embed_table.dtype and image_tokens.shape[-1] == D
-    _lib.call("setok_splice_rows", _stream(), _code(embed_table.dtype), _p(src), _p(embed_table), V, _p(image_tokens), _p(out),
-              B * max_len, D)
+        n_img_rows = image_tokens.shape[0]
+    if status is not None:
+        assert status.dtype == torch.int32 and status.numel() >= 2
+    _lib.call("setok_splice_rows", _stream(), _code(embed_table.dtype), _p(src), _p(embed_table), V, _p(image_tokens), n_img_rows, _p(out),
+              B * max_len, D, _p(status))
     return out
+
+
+def splice_rows_bwd(src: Tensor, d_out: Tensor, n_image_rows: int, want_embed: int = 0) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """(d image_tokens (n_image_rows, D) in d_out's dtype, d embed_table (want_embed, D) fp32 or None)."""
+    rows, D = src.numel(), d_out.shape[-1]
+    d_out = d_out.reshape(rows, D)
+    assert d_out.is_contiguous()
+    dfe = torch.empty((n_image_rows, D), dtype=d_out.dtype, device=d_out.device) if n_image_rows > 0 else None
+    dem = torch.zeros((want_embed, D), dtype=torch.float32, device=d_out.device) if want_embed > 0 else None
+    _lib.call("setok_splice_rows_bwd", _stream(), _code(d_out.dtype), _p(src), _p(d_out), rows, D, _p(dfe), n_image_rows, _p(dem), want_embed)
+    return dfe, dem
 
 
 # ---- backward pass of the trainable head (csrc/backward.hip) ----------------------------------------------------------------

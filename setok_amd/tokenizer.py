@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd, ops
 from ._packcache import PackCacheMixin, f32_of
 from .clip_encoder import CLIPVisionTower
 
@@ -93,10 +93,15 @@ class Block(PackCacheMixin, nn.Module):
             w2=self.mlp.fc2.weight.detach().contiguous(), b2=f32(self.mlp.fc2.bias), eps=self.norm1.eps)
         return self._packed
 
-    @torch.no_grad()
     def forward_rows(self, h: torch.Tensor, seg_offsets: torch.Tensor, n_segs: int, seg_len_bound: int) -> torch.Tensor:
         """Block.forward (module.py:95-100) on packed rows `h` (rows, C), each row attending only within
-        its own segment.  `h` is updated in place and returned."""
+        its own segment.  `h` is updated in place and returned.  Inference arithmetic; the differentiable form of the tokenizer's two
+        Blocks is `SetokTokenizer.encode_features` (autograd.HeadFn)."""
+        autograd.refuse_grad("Block.forward_rows", [h, *self.parameters()], "Train the tokenizer's Blocks through SetokTokenizer.forward / encode_features.")
+        with torch.no_grad():
+            return self._forward_rows(h, seg_offsets, n_segs, seg_len_bound)
+
+    def _forward_rows(self, h, seg_offsets, n_segs, seg_len_bound):
         pk = self._pack()
         H, Dh = self.num_heads, self.dim // self.num_heads
         y = None
@@ -110,7 +115,6 @@ class Block(PackCacheMixin, nn.Module):
         ops.linear(u, pk["w2"], pk["b2"], residual=h, out=h)
         return h
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B, n, C) -> (B, n, C), the reference's call shape."""
         B, n, C = x.shape
@@ -321,10 +325,30 @@ class SetokTokenizer(nn.Module):
         L = int(counts[0])
         return index_down[0, :L], idx[0], score
 
-    @torch.no_grad()
     def encode_features(self, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, token_mask=None,
                         noise=None, return_stages: bool = False):
-        """tokenizer.py:162-180 for a batch, from the tower's hidden rows (B*(N+skip), C)."""
+        """tokenizer.py:162-180 for a batch, from the tower's hidden rows (B*(N+skip), C).
+
+        With gradients enabled and a head parameter (inner_encoder / inter_encoder / out) requiring one, the tokens carry a grad_fn
+        (autograd.HeadFn: the forward keeps its activations, `tokens.backward()` fills the parameters' `.grad`; the clustering is no_grad in
+        the reference too, tokenizer.py:79, and the features are treated as constants: the tower is frozen)."""
+        head = [p for n, p in self.named_parameters() if not n.startswith("image_feature_encoder.")]
+        if autograd.grad_needed(*head):
+            if return_stages:
+                raise NotImplementedError("return_stages is an inference-path diagnostic; call it under torch.no_grad()")
+            autograd.refuse_grad("SetokTokenizer.encode_features (the tower's features are constants of the head's training step)", [hidden_rows])
+            tower = self.image_feature_encoder
+            if tower.select_feature not in ("patch", "cls_patch"):
+                raise ValueError(f"Unexpected select feature: {tower.select_feature}")
+            N = hidden_rows.shape[0] // B - (1 if tower.select_feature == "patch" else 0)
+            if int(math.sqrt(N)) ** 2 != N:
+                raise ValueError(f"{N} tokens do not form a square grid (einops rearrange would fail, tokenizer.py:165)")
+            packed, counts, idx, score = autograd.head_apply(self, hidden_rows, B, k, threshold, noise, token_mask)
+            return RaggedTokens(packed, counts), idx, score.reshape(B, 1, N)
+        with torch.no_grad():
+            return self._encode_features(hidden_rows, B, k, threshold, token_mask, noise, return_stages)
+
+    def _encode_features(self, hidden_rows, B, k, threshold, token_mask, noise, return_stages):
         tower = self.image_feature_encoder
         if tower.select_feature == "patch":
             skip = 1
@@ -347,10 +371,10 @@ class SetokTokenizer(nn.Module):
         counts_h = counts.cpu().tolist()                                           # the one host sync: L_i sizes the ragged output
         total = int(sum(counts_h))
         hs = ops.gather_rows(x, perm)                                              # x[m] for every cluster (:150)
-        hs = self.inner_encoder.forward_rows(hs, seg_offsets, total, N)            # :150
+        hs = self.inner_encoder._forward_rows(hs, seg_offsets, total, N)           # :150
         group = ops.segment_mean(hs, seg_offsets, img_offsets[B:], total)          # :151-153
         stages = dict(x=x, group=group.clone()) if return_stages else None
-        inter = self.inter_encoder.forward_rows(group, img_offsets, B, max(counts_h))   # :179 (+D2)
+        inter = self.inter_encoder._forward_rows(group, img_offsets, B, max(counts_h))   # :179 (+D2)
         tokens = ops.linear(inter, self.out.weight.detach().contiguous(), f32_of(self.out, "bias", self.out.bias))      # :180
         out = (RaggedTokens(tokens, counts_h), idx, score.reshape(B, 1, N))
         if return_stages:
@@ -358,32 +382,45 @@ class SetokTokenizer(nn.Module):
             return out + (stages,)
         return out
 
-    @torch.no_grad()
     def forward(self, x, k=None, threshold=None, token_mask=None, noise=None):
         """images (B, 3, H, W) or a list of (3, H, W) tensors ->
         (image_features: RaggedTokens with B items (L_i, token_feat_dim), idx_cluster (B, N) int64,
          score (B, 1, N)).  `noise` (B, N) replaces the reference's implicit `torch.rand` density
-        tie-break (tokenizer.py:91); None == no noise."""
+        tie-break (tokenizer.py:91); None == no noise.
+
+        Frozen (the reference's stage 2, or any call under torch.no_grad()): ONE library call (`setok_encode`).  With gradients enabled
+        and a head parameter requiring one (the reference's stage 1): the frozen tower runs without a graph and the head through
+        `encode_features`' differentiable form, so `tokens.backward()` / a loss downstream of `encode_images` trains the head."""
         if isinstance(x, (list, tuple)):
             x = torch.stack([im for im in x], dim=0)
         if x.dim() == 3:
             x = x.unsqueeze(0)
         B = x.shape[0]
-        if os.environ.get("SETOK_HOST_PATH", "0") == "1":                          # the same path op by op from Python (A/B runs, tests of the two forms)
-            hidden = self.image_feature_encoder.hidden_rows(x)                     # tokenizer.py:161
+        tower = self.image_feature_encoder
+        autograd.refuse_grad("SetokTokenizer.forward (no gradient flows to the images)", [x])
+        if tower.is_loaded:
+            autograd.refuse_grad("CLIPVisionTower (the ViT tower has no backward pass on the HIP path)", tower.vision_tower.parameters())
+        training_head = autograd.grad_needed(*[p for n, p in self.named_parameters() if not n.startswith("image_feature_encoder.")])
+        if training_head or os.environ.get("SETOK_HOST_PATH", "0") == "1":        # SETOK_HOST_PATH: the same path op by op from Python (A/B runs, tests of the two forms)
+            hidden = tower.hidden_rows(x)                                          # tokenizer.py:161
             if hidden.dtype != self.dtype:
                 hidden = hidden.to(self.dtype)
             return self.encode_features(hidden, B, k, threshold, token_mask, noise)
-        tower = self.image_feature_encoder
-        if not tower.is_loaded:
-            raise RuntimeError("vision tower not loaded: call load_model() first")
-        cfg = tower.config
-        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != cfg.image_size or x.shape[3] != cfg.image_size:
-            raise ValueError(f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
-        if tower.select_feature not in ("patch", "cls_patch"):
-            raise ValueError(f"Unexpected select feature: {tower.select_feature}")
-        tokens, counts, idx, score, _ = self._context().encode(x, k, threshold, noise, token_mask)
-        return RaggedTokens(tokens, counts), idx, score.reshape(B, 1, -1)
+        with torch.no_grad():
+            if not tower.is_loaded:
+                raise RuntimeError("vision tower not loaded: call load_model() first")
+            cfg = tower.config
+            if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != cfg.image_size or x.shape[3] != cfg.image_size:
+                raise ValueError(f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
+            if tower.select_feature not in ("patch", "cls_patch"):
+                raise ValueError(f"Unexpected select feature: {tower.select_feature}")
+            if tower.dtype != self.dtype:
+                # the single-call context runs tower and head in ONE dtype; a mixed setup (fp32 tower under a bf16 head or the reverse) keeps the
+                # reference's arithmetic — the tower in its own dtype, its output cast (clip_encoder.py:60) — on the op-by-op path
+                hidden = tower.hidden_rows(x)
+                return self._encode_features(hidden.to(self.dtype), B, k, threshold, token_mask, noise, False)
+            tokens, counts, idx, score, _ = self._context().encode(x, k, threshold, noise, token_mask)
+            return RaggedTokens(tokens, counts), idx, score.reshape(B, 1, -1)
 
     def __getstate__(self):
         """copy.deepcopy / pickling (EMA copies, `torch.save(module)`): the library-side context is a handle to device memory owned by THIS
@@ -398,7 +435,7 @@ class SetokTokenizer(nn.Module):
         from .context import EncodeContext
         if self.__dict__.get("_ctx_params") is None:
             self.__dict__["_ctx_params"] = list(self.parameters())
-        key = (self.dtype, str(self.device), self.image_feature_encoder.select_layer, self.image_feature_encoder.select_feature,
+        key = (self.dtype, self.image_feature_encoder.dtype, str(self.device), self.image_feature_encoder.select_layer, self.image_feature_encoder.select_feature,
                self.min_cluster_num, float(self.threshold), os.environ.get("SETOK_LN_FOLD", "1"), sum(p._version for p in self._ctx_params),
                tuple(p.data_ptr() for p in self._ctx_params[:4]))
         hit = self.__dict__.get("_ctx")
@@ -408,7 +445,6 @@ class SetokTokenizer(nn.Module):
             self.__dict__["_ctx"] = hit
         return hit[1]
 
-    @torch.no_grad()
     def encode_batch(self, images: torch.Tensor, **kw):
         """Dataset-side contract for a whole batch (pairDataset.py:419-421,445-447 call the tokenizer once per sample from
         DataLoader workers): images (B, 3, H, W) -> (tokens, num_tokens) with tokens[i] = `gen_image` (L_i, D) of sample i and

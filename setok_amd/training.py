@@ -34,17 +34,18 @@ def _k_granule(dtype) -> int:
 # Linear
 # ----------------------------------------------------------------------------------------------------------------------------
 def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[str, torch.Tensor], name: str, need_dx: bool = True,
-               residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+               residual: Optional[torch.Tensor] = None, need_dw: bool = True) -> Optional[torch.Tensor]:
     """y = x w^T + b.  grads[name.weight] = dy^T x (fp32), grads[name.bias] = colsum(dy); returns dx = dy w (+ residual)."""
     pad = _k_granule(x.dtype)
     M, N, K = x.shape[0], dy.shape[1], x.shape[1]
-    # the contraction runs over the M rows; a weight gradient has few output tiles (N x K), so long contractions are split into S
-    # batched partial products summed in a fixed order — enough workgroups to fill the chip, still deterministic
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    S = max(1, min(16, 1024 // max(tiles, 1), M // 2048))
-    (dyT, db), xT = ops.transpose(dy, pad, S, with_colsum=True), ops.transpose(x, pad, S)      # the bias gradient falls out of dY's transpose
-    grads[name + ".weight"] = ops.linear_tn(dyT, xT)
-    grads[name + ".bias"] = db
+    if need_dw:
+        # the contraction runs over the M rows; a weight gradient has few output tiles (N x K), so long contractions are split into S
+        # batched partial products summed in a fixed order — enough workgroups to fill the chip, still deterministic
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        S = max(1, min(16, 1024 // max(tiles, 1), M // 2048))
+        (dyT, db), xT = ops.transpose(dy, pad, S, with_colsum=True), ops.transpose(x, pad, S)      # the bias gradient falls out of dY's transpose
+        grads[name + ".weight"] = ops.linear_tn(dyT, xT)
+        grads[name + ".bias"] = db
     if not need_dx:
         return None
     wT = ops.transpose(w.contiguous())                            # (K, N)
@@ -134,7 +135,8 @@ def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[st
 # the head
 # ----------------------------------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, noise=None, dropout_seed: Optional[int] = None):
+def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k=None, threshold=None, noise=None, dropout_seed: Optional[int] = None,
+                       token_mask=None):
     """tokenizer.py:162-180 for a batch, keeping what the backward pass needs.  Returns (tokens: RaggedTokens, ctx).  `dropout_seed`: run the two
     Blocks in TRAINING mode — nn.Dropout(proj_drop) at its three sites (module.py:36,44,45,59,72) with masks drawn from this seed; None = eval-mode
     arithmetic."""
@@ -146,7 +148,7 @@ def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k
     pos = tok.position_embedding.table(h, w, hidden_rows.dtype, hidden_rows.device)
     x = ops.select_add_pos(hidden_rows, pos, B, N, skip)
     idx, score, index_down, counts = ops.cluster_dpc_knn(x, B, N, k if k else tok.min_cluster_num,
-                                                         threshold if threshold else tok.threshold, tok.min_cluster_num, noise, None)
+                                                         threshold if threshold else tok.threshold, tok.min_cluster_num, noise, token_mask)
     perm, seg_offsets, img_offsets = ops.cluster_sort(idx, counts)
     counts_h = counts.cpu().tolist()
     total = int(sum(counts_h))
@@ -167,7 +169,7 @@ def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k
     w_out = tok.out.weight.detach().contiguous()
     tokens = ops.linear(inter_out, w_out, tok.out.bias.detach().float().contiguous())
     ctx = dict(inner=inner_ctx, inter=inter_ctx, inter_out=inter_out, w_out=w_out, seg_offsets=seg_offsets, img_offsets=img_offsets,
-               total=total, rows=B * N, B=B)
+               total=total, rows=B * N, B=B, idx=idx, score=score)
     return RaggedTokens(tokens, counts_h), ctx
 
 
@@ -310,8 +312,16 @@ class HeadTrainer:
         for n, p in self.params.items():
             ops.adamw(self.master[n].view(-1), self.grads[n].reshape(-1), self.m[n].view(-1), self.v[n].view(-1), p.data.view(-1), self.lr,
                       self.betas[0], self.betas[1], self.eps, self.wd, self.t, scale)
-        self.tok.inner_encoder._packed = {}                          # the packed fp32 biases / LayerNorm affines are copies: re-read them
-        self.tok.inter_encoder._packed = {}
+        # The parameters were rewritten through raw pointers (`p.data.view(-1)`), which does NOT bump their `_version` counters — every cache
+        # keyed on those would keep serving the pre-step weights: the library-side encode context (device COPIES of all weights), the Blocks'
+        # packed fp32 biases / LayerNorm affines, the cached fp32 copies of bf16 biases.  Drop them all.
+        for p in self.params.values():
+            torch.autograd.graph.increment_version(p)                 # what an in-place torch op would have done: every version-keyed cache notices
+        self.tok.__dict__["_ctx"] = None
+        for m in self.tok.modules():
+            m.__dict__.pop("_f32_cache", None)
+            if hasattr(m, "_drop_pack"):
+                m._drop_pack()
 
     def comm_stats(self) -> Dict[str, float]:
         """Of the last step(s): gradient bytes all-reduced per step and the exposed (not overlapped with the backward pass) all-reduce time —

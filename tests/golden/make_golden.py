@@ -314,6 +314,54 @@ def gen_head_grads():
 
 
 # ----------------------------------------------------------------------------------------------
+STAGE2_CASES = {
+    # name: (projector_type, seed, B, T, V, token_feat_dim, hidden, kwargs, train_embed)
+    "mlp2x": ("mlp2x_gelu", 11, 5, 12, 40, 96, 64, dict(), False),
+    "linear_trunc": ("linear", 12, 6, 10, 40, 96, 64, dict(max_length=9), False),
+    "mlp2x_norm_left_embed": ("mlp2x_gelu_Norm", 13, 4, 14, 48, 96, 64, dict(padding_side="left"), True),
+}
+
+
+def gen_stage2():
+    """Stage 2 of the reference's recipe (scripts/pretrain_mm_proj.sh:40): the REFERENCE's build_vision_projector module + the REFERENCE's
+    prepare_inputs_labels_for_multimodal under torch autograd (oracle/rac_harness.py::rac_stage2_grads), a small downstream loss standing in
+    for the LLM.  Stored: the projector's initial weights, the tokens, the downstream matrix, and the reference's loss / inputs_embeds /
+    projector gradients / d loss / d tokens (/ d embed_tokens.weight)."""
+    B_ = R.load_reference_projector_builder()
+    arrs = {}
+    for name, (ptype, seed, B, T, V, Dt, Dh, kw, train_embed) in STAGE2_CASES.items():
+        ids, am, labels, feats, W = O.splice_inputs(seed, B, T, V, Dh)
+        g = torch.Generator().manual_seed(seed + 1000)
+        toks = [torch.randn(f.shape[0], Dt, generator=g) for f in feats]
+        w_down = torch.randn(V, Dh, generator=g) * 0.3
+        torch.manual_seed(seed)
+        proj = B_.build_vision_projector(ptype, mm_hidden_size=Dt, hidden_size=Dh)
+        with torch.no_grad():
+            for p_ in proj.parameters():                       # non-trivial biases / LayerNorm affines
+                if p_.dim() == 1:
+                    p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+        pos = torch.arange(T).expand(B, T).clone()
+        w0 = {n: p_.detach().clone() for n, p_ in proj.named_parameters()}
+        loss, embeds, new_labels, pg, tg, eg = R.rac_stage2_grads(proj, toks, ids, pos, am, labels, W, w_down, train_embed=train_embed, **kw)
+        arrs[name + ":spec"] = np.array([seed, B, T, V, Dt, Dh, kw.get("max_length", -1), 1 if kw.get("padding_side") == "left" else 0, int(train_embed)])
+        arrs[name + ":ptype"] = np.array(ptype)
+        arrs[name + ":w_down"] = npy(w_down)
+        arrs[name + ":loss"] = npy(loss)
+        arrs[name + ":embeds"] = npy(embeds)
+        arrs[name + ":counts"] = np.array([t.shape[0] for t in toks])
+        arrs[name + ":tokens"] = npy(torch.cat(toks, 0))
+        arrs[name + ":dtokens"] = npy(torch.cat(tg, 0))
+        for n, v in w0.items():
+            arrs[f"{name}:w:{n}"] = npy(v)
+        for n, v in pg.items():
+            arrs[f"{name}:g:{n}"] = npy(v)
+        if eg is not None:
+            arrs[name + ":dembed"] = npy(eg)
+        print(name, "loss", float(loss), "embeds", tuple(embeds.shape), "grads", sorted(pg), "zero token-grad rows",
+              int((torch.cat(tg, 0).abs().sum(1) == 0).sum()))
+    save("stage2", **arrs)
+
+
 LLAMA_CASES = {
     # name: (LlamaConfigLite kwargs, seed, B, T, padding)
     "tiny_right": (dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100), 7, 3, 11, "right"),
@@ -401,7 +449,9 @@ def gen_lm_loss():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads", "llama", "lm_loss"]
+    which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads", "llama", "lm_loss", "stage2"]
+    if "stage2" in which:
+        gen_stage2()
     if "detok" in which:
         gen_detok()
     if "splice" in which:

@@ -202,3 +202,25 @@ def test_lm_loss_resized_vocabulary_contiguous_rows(dt, V):
     flat[1:] = dev_logits.reshape(-1)
     out2 = ops.lm_loss(flat[1:].view(B, T, V), labels.to(DEV), am.to(DEV)).cpu()
     assert abs(float(out2[0]) - ref) <= 2e-6 * abs(ref) + 1e-6
+
+
+def test_text_only_prefill_validates_ids_like_embed_tokens():
+    """the text-only branch is `embed_tokens(input_ids)` (setokim_llama.py:118-128 with images None).  An id the table cannot
+    serve — an IMAGE_TOKEN_INDEX although no images came, a leaked TARGET_TOKEN_INDEX, an id >= vocab — raises IndexError like torch's embedding;
+    it must never be decoded as an image-token row of a NULL buffer."""
+    kw = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=4, vocab_size=100)
+    lc = O.LlamaConfigLite(**kw)
+    sd = O.init_llama_weights(lc, seed=11)
+    m = SetokimLlamaPrefill(kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    ids = torch.randint(0, 100, (2, 7), generator=torch.Generator().manual_seed(0))
+    lg, _, _ = m(input_ids=ids.to(DEV))
+    _, ref = O.llama_forward(sd, lc, sd["model.embed_tokens.weight"][ids], None, None)
+    assert _rel(lg.cpu(), ref) < 1e-4
+    for bad in (-200, -300, 100, 12345):
+        ids2 = ids.clone(); ids2[1, 3] = bad
+        with pytest.raises(IndexError, match=r"input_ids\[1, 3\]"):
+            m(input_ids=ids2.to(DEV))
+    lg2, _, _ = m(input_ids=ids.to(DEV))                                  # the context is intact after the refused calls
+    assert torch.equal(lg, lg2)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 import setok_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.grad]        # torch-autograd references + the hand-written backward: gradients stay enabled
 
 if torch.cuda.is_available():
     import setok_amd
