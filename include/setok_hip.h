@@ -282,6 +282,18 @@ int setok_splice_rows(void* stream, int dtype, const int32_t* src, const void* e
 int setok_splice_rows_bwd(void* stream, int dtype, const int32_t* src, const void* d_out, int64_t rows, int D,
                           void* d_image_tokens, int64_t image_token_rows, float* d_embed, int vocab);
 
+/* ---- reconstruction decoder: the output the reference never defines ---------------------------------------------
+ * SetokDeTokenizer.forward ends at decoder_norm and returns None (src/model/setok/detokenizer.py:101-120) while SeTok.forward hands the result
+ * to a pixel-space loss as an image (src/model/setok/model.py:75-76,91).  The pixel head = one setok_linear (decoder_embed_dim -> patch^2 * 3 per
+ * query) + this rearrangement: image[b, c, h*p + pi, w*p + qi] = patches[(b*gh + h)*gw + w, (pi*p + qi)*3 + c]; ld = row stride of `patches`
+ * in elements (>= 3 p^2: the GEMM output may be padded). */
+int setok_unpatchify(void* stream, int dtype, const void* patches, int64_t ld, void* image, int B, int gh, int gw, int p);
+
+/* out[0] = mean over the n elements of (pred - target)^2 (kind 0: WeightedMSELoss without a mask, src/model/loss/mse.py:9-19) or |pred - target|
+ * (kind 1: the pixel term of the GAN loss, src/model/loss/discriminator.py:161,170).  fp32 accumulation in two fixed-order stages (no atomics).
+ * ws: >= 1024 floats of scratch. */
+int setok_pixel_loss(void* stream, int dtype, const void* pred, const void* target, int64_t n, int kind, float* ws, float* out);
+
 /* ---- training step of the trainable head --------------------------------------------------------------
  * The reference trains through torch autograd (src/train/setok_trainer.py / train_setokim.py drive `loss.backward()`); the tower is
  * frozen (clip_encoder.py:50, unfreeze_mm_vision_tower=False) and cluster_dpc_knn is no_grad (tokenizer.py:79), so the backward

@@ -688,6 +688,26 @@ def splice_inputs(seed, B, T, V, D, max_imgs=3, pad=True):
     return ids, am, labels, feats, W
 
 
+# ----------------------------------------------------------------------------------------------
+# §8(f) row 2 — the pixel head the reference never defines.  SetokDeTokenizer.forward returns None after decoder_norm
+# (detokenizer.py:101-120) while SeTok.forward passes the result to a pixel-space loss as an image (model.py:75-76,91): the build's
+# definition is `to_pixels` (Linear decoder_embed_dim -> patch^2 * 3 per query) + the rearrangement below + the reference's own pixel terms.
+# ----------------------------------------------------------------------------------------------
+def unpatchify(patches: Tensor, B: int, gh: int, gw: int, p: int) -> Tensor:
+    """(B*gh*gw, 3 p^2) rows with columns (pi, qi, c), c fastest -> (B, 3, gh*p, gw*p): 'n (h w) (p q c) -> n c (h p) (w q)'."""
+    x = patches.reshape(B, gh, gw, p, p, 3)
+    return torch.einsum("nhwpqc->nchpwq", x).reshape(B, 3, gh * p, gw * p)
+
+
+def pixel_loss(pred: Tensor, target: Tensor, kind: str = "mse") -> Tensor:
+    """"mse": WeightedMSELoss.forward without a mask (src/model/loss/mse.py:9-19, weight 1): nn.MSELoss(reduction='none'), mean over
+    (C, H, W), mean over the batch.  "l1": the pixel term of the GAN loss, torch.abs(inputs - reconstructions) then torch.mean
+    (src/model/loss/discriminator.py:161,170)."""
+    if kind == "mse":
+        return ((pred - target) ** 2).mean([-3, -2, -1]).mean()
+    return torch.abs(target - pred).mean()
+
+
 def stage2_downstream(embeds, new_labels, w_down):
     """The small stand-in for the LLM behind inputs_embeds in the stage-2 gradient tests (test infrastructure, shared by the golden generator —
     where it sits behind the REFERENCE's projector and splice — and the GPU test): a tanh, a vocabulary projection, the shifted cross entropy of

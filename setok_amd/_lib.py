@@ -58,6 +58,8 @@ SIGNATURES = {
     "setok_segment_mean": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i],
     "setok_splice_lengths": [_vp, _vp, _vp, _i, _i, _i64, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "setok_splice_plan": [_vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "setok_unpatchify": [_vp, _i, _vp, _i64, _vp, _i, _i, _i, _i],
+    "setok_pixel_loss": [_vp, _i, _vp, _vp, _i64, _i, _vp, _vp],
     "setok_transpose": [_vp, _i, _vp, _i64, _i, _i, _vp, _i64, _i, _vp],
     "setok_colsum": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i],
     "setok_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i],

@@ -253,3 +253,74 @@ extern "C" int setok_dropout(void* stream, int dtype, const void* x, const void*
     SETOK_CHECK_LAUNCH("setok_dropout");
     return SETOK_OK;
 }
+
+// ---- reconstruction decoder, the output the reference never defines -------------------------------------------------
+// SetokDeTokenizer.forward ends at decoder_norm and returns None (detokenizer.py:101-120) although SeTok.forward hands its result to a
+// pixel-space loss as an IMAGE (`self.rec_loss(target, prediction, ...)`, model.py:75-76,91).  The head defined here is the standard one of
+// a ViT pixel decoder: a Linear decoder_embed_dim -> patch^2 * 3 per query (a setok_linear call), this rearrangement, and the reference's own
+// pixel terms as one scalar.
+// unpatchify: patches (B * gh * gw, ld), row = one query, columns (pi, qi, c) with c fastest -> image (B, 3, gh * p, gw * p):
+//   image[b, c, h * p + pi, w * p + qi] = patches[(b * gh + h) * gw + w, (pi * p + qi) * 3 + c]        ('n h w p q c -> n c (h p) (w q)')
+template <typename T>
+__global__ __launch_bounds__(256) void unpatchify_kernel(const T* __restrict__ patches, int64_t ld, T* __restrict__ img, int B, int gh, int gw, int p) {
+    const int W = gw * p, Hh = gh * p;
+    const int64_t n = (int64_t)B * 3 * Hh * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % Hh), c = (int)((i / ((int64_t)W * Hh)) % 3), b = (int)(i / ((int64_t)3 * W * Hh));
+        const int h = y / p, pi = y - h * p, w = x / p, qi = x - w * p;
+        img[i] = patches[((int64_t)(b * gh + h) * gw + w) * ld + (pi * p + qi) * 3 + c];
+    }
+}
+
+extern "C" int setok_unpatchify(void* stream, int dtype, const void* patches, int64_t ld, void* image, int B, int gh, int gw, int p) {
+    SETOK_CHECK_ARG(patches && image, "setok_unpatchify: null operand");
+    SETOK_CHECK_ARG(B > 0 && gh > 0 && gw > 0 && p > 0 && ld >= (int64_t)p * p * 3, "setok_unpatchify: bad shape B=%d grid=%dx%d p=%d ld=%lld", B, gh, gw, p, (long long)ld);
+    const int64_t n = (int64_t)B * 3 * gh * p * gw * p;
+    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) unpatchify_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)patches, ld, (bf16*)image, B, gh, gw, p);
+    else if (dtype == SETOK_F32) unpatchify_kernel<float><<<grid, 256, 0, s>>>((const float*)patches, ld, (float*)image, B, gh, gw, p);
+    else return setok_fail(SETOK_EINVAL, "setok_unpatchify: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_unpatchify");
+    return SETOK_OK;
+}
+
+// pixel loss: out[0] = mean_i f(pred_i - target_i), f = square (kind 0: WeightedMSELoss without a mask, loss/mse.py:9-19 — the mean over
+// (C, H, W) and then over the batch of equally sized images is the mean over all elements) or abs (kind 1: the pixel term of the GAN loss,
+// loss/discriminator.py:161,170).  fp32 accumulation, two fixed-order stages (no atomics): bit-identical from run to run.
+constexpr int PL_BLOCKS = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_loss_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, int kind, float* __restrict__ part) {
+    __shared__ float sw[4];
+    const int64_t per = (n + PL_BLOCKS - 1) / PL_BLOCKS, lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float acc = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float d = Elem<T>::ld(a + i) - Elem<T>::ld(b + i);
+        acc += kind == 0 ? d * d : fabsf(d);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void pixel_loss_final_kernel(const float* __restrict__ part, int64_t n, float* __restrict__ out) {
+    __shared__ float sw[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < PL_BLOCKS; i += 256) acc += part[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((sw[0] + sw[1]) + (sw[2] + sw[3])) / (float)n;
+}
+
+extern "C" int setok_pixel_loss(void* stream, int dtype, const void* pred, const void* target, int64_t n, int kind, float* ws, float* out) {
+    SETOK_CHECK_ARG(pred && target && ws && out, "setok_pixel_loss: null operand");
+    SETOK_CHECK_ARG(n > 0 && (kind == 0 || kind == 1), "setok_pixel_loss: bad n=%lld kind=%d", (long long)n, kind);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) pixel_loss_partial_kernel<bf16><<<PL_BLOCKS, 256, 0, s>>>((const bf16*)pred, (const bf16*)target, n, kind, ws);
+    else if (dtype == SETOK_F32) pixel_loss_partial_kernel<float><<<PL_BLOCKS, 256, 0, s>>>((const float*)pred, (const float*)target, n, kind, ws);
+    else return setok_fail(SETOK_EINVAL, "setok_pixel_loss: bad dtype %d", dtype);
+    pixel_loss_final_kernel<<<1, 256, 0, s>>>(ws, n, out);
+    SETOK_CHECK_LAUNCH("setok_pixel_loss");
+    return SETOK_OK;
+}

@@ -188,7 +188,13 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
                  num_hidden_layers: Optional[int] = 6,
                  cross_attention_freq: Optional[int] = 2,
                  initializer_range: Optional[float] = 0.02,
+                 pixel_head: bool = False,
                  **kwargs) -> None:
+        """Same kwargs as the reference (detokenizer.py:14-31) + `pixel_head` (default False: the reference's parameter tree, key for key).
+        With `pixel_head=True` the module also owns `to_pixels = Linear(decoder_embed_dim, patch_size^2 * 3)` — the output the reference never
+        defines: its forward stops at decoder_norm and returns None (detokenizer.py:101-120) although SeTok.forward passes the result to a
+        pixel-space loss as an image (model.py:75-76,91).  `decode_image` / `reconstruction_loss` use it; the GAN / LPIPS
+        terms of the reference's loss stay out of scope (SURVEY.md §2 "OUT")."""
         super().__init__()
         if norm_layer is not nn.LayerNorm:
             raise ValueError("only nn.LayerNorm is implemented on the HIP path")
@@ -223,6 +229,7 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
         self.decoder_norm = norm_layer(decoder_embed_dim)
         self.pixel_decoder = nn.ModuleList([VitBlock(decoder_embed_dim, decoder_nheads, mlp_ratio, norm_layer)
                                             for _ in range(decoder_depth)])
+        self.to_pixels = nn.Linear(decoder_embed_dim, patch_size * patch_size * 3) if pixel_head else None
         self.initialize_weights()                                                  # before the mapper exists, as in the reference (:53-54)
         self.mapper = BertModel(cfg)
         self._init_pack_cache()
@@ -273,7 +280,16 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
             layers.append(d)
         blocks = [dict(n1=ln(b.norm1), qkv=lin(b.attn.qkv), proj=lin(b.attn.proj), n2=ln(b.norm2), fc1=lin(b.mlp.fc1),
                        fc2=lin(b.mlp.fc2)) for b in self.pixel_decoder]
-        self._packed = dict(key=key, fc_in=lin(self.mapper_fc_in), emb_ln=ln(self.mapper.embeddings.LayerNorm), layers=layers,
+        pix = None
+        if self.to_pixels is not None:                                             # rows padded to a multiple of 64 (3 p^2 = 588 at p = 14): aligned GEMM output rows
+            n_out = self.to_pixels.out_features
+            n_pad = (n_out + 63) // 64 * 64
+            wpx = torch.zeros((n_pad, self.decoder_embed_dim), dtype=w.dtype, device=w.device)
+            wpx[:n_out] = self.to_pixels.weight.detach()
+            bpx = torch.zeros((n_pad,), dtype=torch.float32, device=w.device)
+            bpx[:n_out] = self.to_pixels.bias.detach().float()
+            pix = (wpx, bpx)
+        self._packed = dict(key=key, pix=pix, fc_in=lin(self.mapper_fc_in), emb_ln=ln(self.mapper.embeddings.LayerNorm), layers=layers,
                             dec_in=lin(self.decoder_fc_in), blocks=blocks, dec_ln=ln(self.decoder_norm),
                             queries=self.mask_tokens.detach()[0].contiguous())
         return self._packed
@@ -378,3 +394,26 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
             stages["out"] = out
             return stages
         return out
+
+    # -- the pixel head ("define the missing return / pixel head explicitly") ------------------------------------------
+    def decode_image(self, x, attention_masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tokens -> reconstructed image (B, 3, height * patch_size, weight * patch_size): forward(), then `to_pixels` per query and the
+        'n (h w) (p q c) -> n c (h p) (w q)' rearrangement (ops.unpatchify)."""
+        if self.to_pixels is None:
+            raise RuntimeError("this SetokDeTokenizer was built without pixel_head=True: there is no `to_pixels` layer (the reference defines none)")
+        feats = self.forward(x, attention_masks)                                    # (B, Q, D); refuses a gradient like every inference module
+        with torch.no_grad():
+            B, Q, D = feats.shape
+            pk = self._pack()
+            patches = ops.linear(feats.reshape(B * Q, D), *pk["pix"])
+            return ops.unpatchify(patches, B, self.height, self.weight, self.patch_size)
+
+    def reconstruction_loss(self, x, gold_image: torch.Tensor, attention_masks: Optional[torch.Tensor] = None, kind: str = "mse") -> torch.Tensor:
+        """The pixel term of the reference's reconstruction objective between decode_image(x) and `gold_image` (B, 3, H, W) as a 0-d fp32 tensor:
+        "mse" = WeightedMSELoss without a mask (src/model/loss/mse.py:9-19), "l1" = the |input - reconstruction| mean of the GAN loss
+        (src/model/loss/discriminator.py:161,170).  LPIPS and the adversarial term are out of scope."""
+        img = self.decode_image(x, attention_masks)
+        if tuple(gold_image.shape) != tuple(img.shape):
+            raise ValueError(f"gold_image has shape {tuple(gold_image.shape)}, the decoder reconstructs {tuple(img.shape)}")
+        with torch.no_grad():
+            return ops.pixel_loss(img, gold_image.to(device=img.device, dtype=img.dtype).contiguous(), kind)

@@ -335,6 +335,25 @@ def splice_rows_bwd(src: Tensor, d_out: Tensor, n_image_rows: int, want_embed: i
     return dfe, dem
 
 
+# ---- pixel head of the reconstruction decoder (include/setok_hip.h: the output the reference never defines) ---------------------------------
+def unpatchify(patches: Tensor, B: int, gh: int, gw: int, p: int) -> Tensor:
+    """patches (B*gh*gw, >= 3 p^2) -> image (B, 3, gh*p, gw*p); only the first 3 p^2 columns are read (a padded GEMM output is fine)."""
+    assert patches.dim() == 2 and patches.shape[0] == B * gh * gw and patches.shape[1] >= 3 * p * p and patches.stride(1) == 1
+    img = torch.empty((B, 3, gh * p, gw * p), dtype=patches.dtype, device=patches.device)
+    assert patches.is_cuda
+    _lib.call("setok_unpatchify", _stream(), _code(patches.dtype), patches.data_ptr(), patches.stride(0), _p(img), B, gh, gw, p)
+    return img
+
+
+def pixel_loss(pred: Tensor, target: Tensor, kind: str = "mse") -> Tensor:
+    """0-d fp32 tensor: mean squared ("mse") or mean absolute ("l1") difference over all elements."""
+    assert pred.shape == target.shape and pred.dtype == target.dtype and kind in ("mse", "l1")
+    out = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    _lib.call("setok_pixel_loss", _stream(), _code(pred.dtype), _p(pred.contiguous()), _p(target.contiguous()), pred.numel(), 0 if kind == "mse" else 1,
+              _p(_ws(pred.device, 1024)), _p(out))
+    return out[0]
+
+
 # ---- backward pass of the trainable head (csrc/backward.hip) ----------------------------------------------------------------
 def transpose(x: Tensor, pad_to: int = 1, splits: int = 1, with_colsum: bool = False):
     """(rows, cols) -> (cols, P) with P = rows zero-padded to a multiple of pad_to: the A / W operand of a dW = dY^T X GEMM.
