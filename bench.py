@@ -65,15 +65,16 @@ WORKLOADS = {
                               "bf16 weights): 32 images -> SeTok encode (cfg2 model) -> mm_in_projector -> splice into 512-token prompts -> LLM prefill -> "
                               "logits at every position -> language-model loss over the answer part (setokim_llama.py:94-160; the diffusion term is out of scope)"),
     "cfg3": (224, 256, True, "cfg3: cfg2 encode + reconstruction decoder (SetokDeTokenizer: token_feat_dim 4096 -> Q-Former 768/12 heads/6 layers, "
-                              "324 queries (image_size 256 / 14), cross-attention every 2nd layer -> 16 x ViT block 768/16 heads -> LayerNorm); "
-                              "no loss (the reference's GANLoss path is out of scope)"),
+                              "324 queries (image_size 256 / 14), cross-attention every 2nd layer -> 16 x ViT block 768/16 heads -> LayerNorm -> "
+                              "to_pixels (768 -> 14*14*3) -> unpatchify to 252x252 -> mean-squared reconstruction error against a synthetic gold image "
+                              "(the pixel head the reference leaves undefined, detokenizer.py:101-120; its GAN / LPIPS terms are out of scope)"),
 }
 
 
 def build_decoder(device):
     import setok_amd
     det = setok_amd.SetokDeTokenizer(token_feat_dim=4096, hidden_dim=768, patch_size=14, image_size=256, decoder_embed_dim=768,
-                                     decoder_nheads=16, decoder_depth=16, feature_mapper_path_or_name="bert-base-uncased")
+                                     decoder_nheads=16, decoder_depth=16, feature_mapper_path_or_name="bert-base-uncased", pixel_head=True)
     return det.to(device=device, dtype=torch.bfloat16).eval()
 
 
@@ -339,13 +340,17 @@ def main():
         if det is None:
             return setok_amd.encode_images(tok, proj, images)
         tokens, _, _ = tok(images)                   # SeTok.forward (src/model/setok/model.py:87-88): tokenize, then detokenize
-        step.recon = det(tokens)
+        step.recon_loss = det.reconstruction_loss(tokens, step.gold)     # decoder -> to_pixels -> unpatchify -> MSE (model.py:75-76,91)
         return tokens
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if det is not None:                          # the gold image the reconstruction is scored against (ImageNet stand-in at the decoder's 18 x 14 = 252 px)
+        side = det.height * det.patch_size
+        step.gold = torch.randn(B, 3, side, side, generator=torch.Generator().manual_seed(7 + rank)).to(device=dev, dtype=dtype)
 
     for i in range(args.warmup):
         out = step()
@@ -461,6 +466,10 @@ def main():
                 res["roofline"]["frac_at_measured_clock"] = round(achieved / pk, 4)
         if other:
             res["config"]["also_select_layer_minus1"] = other
+        if det is not None:
+            res["config"]["reconstruction_mse"] = round(float(step.recon_loss), 6)      # the step's terminal scalar (random-init decoder vs a random gold image)
+        if llm is not None:
+            res["config"]["lm_loss"] = round(float(step.loss), 6)
         if not args.no_cpu_baseline and not args.timed_only and world == 1 and args.workload == "cfg2":
             res["cpu_baseline"] = cpu_baseline(tok, proj)
         else:

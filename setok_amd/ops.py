@@ -355,7 +355,7 @@ def pixel_loss(pred: Tensor, target: Tensor, kind: str = "mse") -> Tensor:
 
 
 # ---- backward pass of the trainable head (csrc/backward.hip) ----------------------------------------------------------------
-def transpose(x: Tensor, pad_to: int = 1, splits: int = 1, with_colsum: bool = False):
+def transpose(x: Tensor, pad_to: int = 1, splits: int = 1, with_colsum: bool = False, colsum_out: Optional[Tensor] = None):
     """(rows, cols) -> (cols, P) with P = rows zero-padded to a multiple of pad_to: the A / W operand of a dW = dY^T X GEMM.
     splits > 1: P is padded to splits * chunk (chunk a multiple of pad_to) and the result is (splits, cols, chunk) — the split-K layout.
     with_colsum: also returns the fp32 column sums of x (the bias gradient when x is dY), computed inside the same pass."""
@@ -372,21 +372,23 @@ def transpose(x: Tensor, pad_to: int = 1, splits: int = 1, with_colsum: bool = F
     _lib.call("setok_transpose", _stream(), _code(x.dtype), _p(x), cols, rows, cols, _p(out), ldo, chunk, _p(part))
     if not with_colsum:
         return out
-    return out, colsum(part)
+    return out, colsum(part, out=colsum_out)
 
 
-def linear_tn(aT: Tensor, bT: Tensor) -> Tensor:
+def linear_tn(aT: Tensor, bT: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """dW = sum_s aT[s] @ bT[s]^T in fp32 for split-K operands aT (S, N, chunk), bT (S, K, chunk) from `transpose(..., splits=S)`
     (or 2-D (N, P), (K, P) for S = 1): one batched GEMM for the partial products, then a fixed-order sum over the splits."""
     if aT.dim() == 2:
-        return linear(aT, bT, out_dtype=torch.float32)
+        return linear(aT, bT, out=out, out_dtype=torch.float32)
     S, N, chunk = aT.shape
     S2, K, chunk2 = bT.shape
     assert S == S2 and chunk == chunk2 and aT.dtype == bT.dtype
     part = torch.empty((S, N, K), dtype=torch.float32, device=aT.device)
     _lib.call("setok_linear", _stream(), _code(aT.dtype), F32, _p(aT), chunk, _p(bT), None, None, _p(part), K, N, K, chunk, ACT_NONE, S,
               N * chunk, K * chunk, N * K)
-    out = torch.empty((N, K), dtype=torch.float32, device=aT.device)
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=aT.device)
+    assert out.shape == (N, K) and out.dtype == torch.float32 and out.is_contiguous()
     ws = _ws(aT.device, N * K)
     _lib.call("setok_colsum", _stream(), F32, _p(part), S, N * K, _p(out), 0, _p(ws), 1)
     return out

@@ -76,6 +76,65 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int 
     return n_coll
 
 
+class GradBuckets:
+    """Pre-allocated flat fp32 gradient buckets with one view per parameter — the layout DeepSpeed ZeRO-2's `reduce_bucket_size` /
+    `contiguous_gradients` give the reference (scripts/zero2.json:16-22).  The hand-written backward writes every gradient straight into its
+    view (`view(name)`), so a module's all-reduce is a collective on the bucket itself: no concatenation before and no copy back after it
+    (round 2 did both: two extra passes over 151 MB per step).  `modules`: {module name: [(parameter name, shape), ...]} in the order the
+    backward pass completes them; a module larger than `bucket_bytes` is split at parameter boundaries (xGMI is point-to-point and a ring is
+    per-link bound: few large buckets)."""
+
+    def __init__(self, modules, bucket_bytes: int = 64 << 20, device=None):
+        self.flat = {}                 # module -> [flat fp32 tensors]
+        self._views = {}               # parameter name -> view
+        self.order = []                # (module, bucket index) in creation order == reduction order
+        for mod, plist in modules.items():
+            groups, cur, size = [], [], 0
+            for name, shape in plist:
+                n = 1
+                for d in shape:
+                    n *= int(d)
+                if cur and (size + n) * 4 > bucket_bytes:
+                    groups.append(cur); cur, size = [], 0
+                cur.append((name, tuple(shape), n)); size += n
+            if cur:
+                groups.append(cur)
+            self.flat[mod] = []
+            for gi, grp in enumerate(groups):
+                pad = [(n + 63) // 64 * 64 for _, _, n in grp]                      # every view starts on a 256-byte boundary (16-byte vector stores)
+                buf = torch.zeros((sum(pad),), dtype=torch.float32, device=device)
+                off = 0
+                for (name, shape, n), pn in zip(grp, pad):
+                    self._views[name] = buf[off: off + n].view(shape)
+                    off += pn
+                self.flat[mod].append(buf)
+                self.order.append((mod, gi))
+
+    def view(self, name: str, shape=None) -> torch.Tensor:
+        v = self._views[name]
+        if shape is not None and tuple(v.shape) != tuple(shape):
+            raise ValueError(f"gradient bucket view {name}: shape {tuple(v.shape)}, asked for {tuple(shape)}")
+        return v
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._views
+
+    def names(self):
+        return list(self._views)
+
+    def nbytes(self, mod: str) -> int:
+        return sum(b.numel() * 4 for b in self.flat[mod])
+
+    def allreduce(self, mod: str, group=None, average: bool = False) -> int:
+        """Sum (or mean) every bucket of `mod` over the data-parallel group IN PLACE; returns the number of collectives."""
+        world = dist.get_world_size(group)
+        for buf in self.flat[mod]:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                buf.div_(world)
+        return len(self.flat[mod])
+
+
 def max_over_ranks(seconds: float, device=None, group=None) -> float:
     """The benchmark's timing rule: wall time of the slowest rank."""
     if not (dist.is_available() and dist.is_initialized()):

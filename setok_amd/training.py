@@ -34,8 +34,9 @@ def _k_granule(dtype) -> int:
 # Linear
 # ----------------------------------------------------------------------------------------------------------------------------
 def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[str, torch.Tensor], name: str, need_dx: bool = True,
-               residual: Optional[torch.Tensor] = None, need_dw: bool = True) -> Optional[torch.Tensor]:
-    """y = x w^T + b.  grads[name.weight] = dy^T x (fp32), grads[name.bias] = colsum(dy); returns dx = dy w (+ residual)."""
+               residual: Optional[torch.Tensor] = None, need_dw: bool = True, alloc=None) -> Optional[torch.Tensor]:
+    """y = x w^T + b.  grads[name.weight] = dy^T x (fp32), grads[name.bias] = colsum(dy); returns dx = dy w (+ residual).
+    `alloc(parameter name, shape)`: where a gradient is to be written (a view of a flat all-reduce bucket, parallel.GradBuckets); None = fresh tensors."""
     pad = _k_granule(x.dtype)
     M, N, K = x.shape[0], dy.shape[1], x.shape[1]
     if need_dw:
@@ -43,8 +44,10 @@ def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[s
         # batched partial products summed in a fixed order — enough workgroups to fill the chip, still deterministic
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         S = max(1, min(16, 1024 // max(tiles, 1), M // 2048))
-        (dyT, db), xT = ops.transpose(dy, pad, S, with_colsum=True), ops.transpose(x, pad, S)      # the bias gradient falls out of dY's transpose
-        grads[name + ".weight"] = ops.linear_tn(dyT, xT)
+        wo = alloc(name + ".weight", (N, K)) if alloc else None
+        bo = alloc(name + ".bias", (N,)) if alloc else None
+        (dyT, db), xT = ops.transpose(dy, pad, S, with_colsum=True, colsum_out=bo), ops.transpose(x, pad, S)      # the bias gradient falls out of dY's transpose
+        grads[name + ".weight"] = ops.linear_tn(dyT, xT, out=wo)
         grads[name + ".bias"] = db
     if not need_dx:
         return None
@@ -98,7 +101,7 @@ def block_forward_train(blk: Block, x: torch.Tensor, seg_offsets: torch.Tensor, 
     return out, ctx
 
 
-def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[str, torch.Tensor], need_dx: bool) -> Optional[torch.Tensor]:
+def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[str, torch.Tensor], need_dx: bool, alloc=None) -> Optional[torch.Tensor]:
     """g = dL/d(block output).  Fills grads[prefix + <reference parameter name>]; returns dL/d(block input) if need_dx."""
     pk = blk._pack()
     H, Dh = blk.num_heads, blk.dim // blk.num_heads
@@ -109,22 +112,28 @@ def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[st
     depth = len(pk["attn"])
     # Mlp: out = xd + drop(fc2(drop(gelu(fc1(norm2(xd))))))  — a dropout's backward is the same mask and scale on the gradient
     gf = g if drop is None else ops.dropout(g, drop.p, drop.seed, drop.offset(depth + 1))
-    du = linear_bwd(ctx["u"], pk["w2"], gf, grads, prefix + "mlp.fc2")
+    du = linear_bwd(ctx["u"], pk["w2"], gf, grads, prefix + "mlp.fc2", alloc=alloc)
     if drop is not None:
         du = ops.dropout(du, drop.p, drop.seed, drop.offset(depth), out=du)
     dpre = ops.gelu_bwd(ctx["pre"], du)
-    dy2 = linear_bwd(ctx["y2"], pk["w1"], dpre, grads, prefix + "mlp.fc1")
-    g2w = torch.empty((C,), dtype=torch.float32, device=dev); g2b = torch.empty_like(g2w)
+    dy2 = linear_bwd(ctx["y2"], pk["w1"], dpre, grads, prefix + "mlp.fc1", alloc=alloc)
+    if alloc:
+        g2w, g2b = alloc(prefix + "norm2.weight", (C,)), alloc(prefix + "norm2.bias", (C,))
+    else:
+        g2w = torch.empty((C,), dtype=torch.float32, device=dev); g2b = torch.empty_like(g2w)
     g = ops.layernorm_bwd(ctx["xd"], dy2, pk["n2"][0], pk["eps"], g2w, g2b, accumulate=False, res=g)      # dL/dxd = g + LN2'(dy2)
     grads[prefix + "norm2.weight"], grads[prefix + "norm2.bias"] = g2w, g2b
-    g1w = torch.zeros((C,), dtype=torch.float32, device=dev); g1b = torch.zeros_like(g1w)                # shared norm1 accumulates
+    if alloc:                                                                                              # shared norm1 accumulates
+        g1w, g1b = alloc(prefix + "norm1.weight", (C,)).zero_(), alloc(prefix + "norm1.bias", (C,)).zero_()
+    else:
+        g1w = torch.zeros((C,), dtype=torch.float32, device=dev); g1b = torch.zeros_like(g1w)
     for i in reversed(range(depth)):
         a = pk["attn"][i]
         lp = prefix + f"layers.{i}.1."
         gp = g if drop is None else ops.dropout(g, drop.p, drop.seed, drop.offset(i))
-        do = linear_bwd(ctx["o"][i], a["wproj"], gp, grads, lp + "proj")
+        do = linear_bwd(ctx["o"][i], a["wproj"], gp, grads, lp + "proj", alloc=alloc)
         dqkv = ops.attention_bwd(ctx["qkv"][i], ctx["o"][i], do, H, Dh, a["scale"], seg_bound, seg_offsets, n_segs)
-        dy = linear_bwd(ctx["y"][i], a["wqkv"], dqkv, grads, lp + "qkv")
+        dy = linear_bwd(ctx["y"][i], a["wqkv"], dqkv, grads, lp + "qkv", alloc=alloc)
         last = i == 0 and not need_dx
         g = ops.layernorm_bwd(ctx["x"][i], dy, pk["n1"][0], pk["eps"], g1w, g1b, accumulate=True, need_dx=not last, res=g)
     grads[prefix + "norm1.weight"], grads[prefix + "norm1.bias"] = g1w, g1b
@@ -174,8 +183,8 @@ def head_forward_train(tok: SetokTokenizer, hidden_rows: torch.Tensor, B: int, k
 
 
 @torch.no_grad()
-def head_backward(tok: SetokTokenizer, ctx, dtokens: torch.Tensor, on_module_done: Optional[Callable[[str, Dict[str, torch.Tensor]], None]] = None
-                  ) -> Dict[str, torch.Tensor]:
+def head_backward(tok: SetokTokenizer, ctx, dtokens: torch.Tensor, on_module_done: Optional[Callable[[str, Dict[str, torch.Tensor]], None]] = None,
+                  alloc=None) -> Dict[str, torch.Tensor]:
     """dtokens: (sum L_i, token_feat_dim) = dL/dtokens in the packed order of the forward's RaggedTokens.  Returns fp32 gradients
     under the reference's parameter names.  `on_module_done(module, grads_of_that_module)` fires as soon as a module's gradients
     are complete (out, then inter_encoder, then inner_encoder) — the hook the overlapped all-reduce hangs on."""
@@ -186,12 +195,12 @@ def head_backward(tok: SetokTokenizer, ctx, dtokens: torch.Tensor, on_module_don
             on_module_done(mod, {n: g for n, g in grads.items() if n.startswith(mod + ".")})
 
     dtokens = dtokens.to(ctx["inter_out"].dtype).contiguous()
-    g = linear_bwd(ctx["inter_out"], ctx["w_out"], dtokens, grads, "out")
+    g = linear_bwd(ctx["inter_out"], ctx["w_out"], dtokens, grads, "out", alloc=alloc)
     done("out")
-    g = block_backward(tok.inter_encoder, "inter_encoder.", ctx["inter"], g, grads, need_dx=True)
+    g = block_backward(tok.inter_encoder, "inter_encoder.", ctx["inter"], g, grads, need_dx=True, alloc=alloc)
     done("inter_encoder")
     g = ops.segment_mean_bwd(g, ctx["seg_offsets"], ctx["img_offsets"][ctx["B"]:], ctx["total"], ctx["rows"])
-    block_backward(tok.inner_encoder, "inner_encoder.", ctx["inner"], g, grads, need_dx=False)
+    block_backward(tok.inner_encoder, "inner_encoder.", ctx["inner"], g, grads, need_dx=False, alloc=alloc)
     done("inner_encoder")
     return grads
 
@@ -239,6 +248,12 @@ class HeadTrainer:
         self.m = {n: torch.zeros_like(v) for n, v in self.master.items()}
         self.v = {n: torch.zeros_like(v) for n, v in self.master.items()}
         self.grads: Dict[str, torch.Tensor] = {}
+        # one flat fp32 bucket (or a few, <= bucket_bytes each) per module, a view per parameter: the backward pass writes the gradients in
+        # place and a module's all-reduce runs on the bucket itself (scripts/zero2.json:16-22: contiguous_gradients + reduce_bucket_size)
+        from .parallel import GradBuckets
+        dev = next(iter(self.params.values())).device
+        self.buckets = GradBuckets({m: [(n, tuple(p.shape)) for n, p in self.params.items() if n.split(".")[0] == m] for m in HEAD_MODULES},
+                                   bucket_bytes=bucket_bytes, device=dev)
         self._comm_stream = None
         self._pending: List = []
         self._comm_bytes = 0                                            # gradient bytes handed to the all-reduce in the current step
@@ -251,26 +266,35 @@ class HeadTrainer:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def _allreduce_module(self, mod: str, g: Dict[str, torch.Tensor]) -> None:
-        """Sum-all-reduce one module's gradients as flat buckets on the communication stream (RCCL over xGMI: point-to-point links,
-        a ring is per-link bound, so few large buckets), while the compute stream carries on with the next module's backward."""
+        """Sum-all-reduce one module's gradients on the communication stream (RCCL over xGMI: point-to-point links, a ring is per-link bound,
+        so few large buckets), while the compute stream carries on with the next module's backward.  When the gradients live in this
+        trainer's flat buckets (the normal case: head_backward wrote them through `self.buckets.view`) the collective runs on the bucket
+        itself — zero-copy; gradients handed in as free tensors take the concatenating path of parallel.allreduce_gradients."""
         if not g:
             return
         names = sorted(g)
         self._comm_bytes += sum(g[n].numel() * g[n].element_size() for n in names)      # what a data-parallel step reduces (counted at any world size)
         if self.world == 1:
             return
-        import torch.distributed as dist
         from .parallel import allreduce_gradients
+        bk = getattr(self, "buckets", None)
+        in_buckets = bk is not None and all(n in bk and g[n].data_ptr() == bk.view(n).data_ptr() for n in names)
+
+        def reduce_():
+            if in_buckets:
+                bk.allreduce(mod, group=self.group, average=False)
+            else:
+                allreduce_gradients([g[n] for n in names], group=self.group, bucket_bytes=self.bucket_bytes, average=False)
         if g[names[0]].is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
-                allreduce_gradients([g[n] for n in names], group=self.group, bucket_bytes=self.bucket_bytes, average=False)
+                reduce_()
                 ev = torch.cuda.Event(); ev.record(self._comm_stream)
             self._pending.append(ev)
         else:
-            allreduce_gradients([g[n] for n in names], group=self.group, bucket_bytes=self.bucket_bytes, average=False)
+            reduce_()
 
     # -- the step -------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -292,9 +316,11 @@ class HeadTrainer:
 
     @torch.no_grad()
     def backward(self, ctx, dtokens: torch.Tensor) -> Dict[str, torch.Tensor]:
+        for ev in self._pending:                                      # a backward without a step() in between: its all-reduce still reads the buckets
+            torch.cuda.current_stream().wait_event(ev)
         self._pending = []
         self._comm_bytes = 0
-        self.grads = head_backward(self.tok, ctx, dtokens, on_module_done=self._allreduce_module)
+        self.grads = head_backward(self.tok, ctx, dtokens, on_module_done=self._allreduce_module, alloc=self.buckets.view)
         return self.grads
 
     @torch.no_grad()

@@ -346,3 +346,16 @@ def test_llama_7b_dims_matches_hf(golden_dir):
     torch.testing.assert_close(logits[:, :, ::stride][valid], _t(z["logits_cols"])[valid], rtol=1e-5, atol=1e-5)
     for b, t in enumerate(_t(z["last"]).tolist()):
         torch.testing.assert_close(logits[b, t], _t(z["logits_last"])[b], rtol=1e-5, atol=1e-5)
+
+
+def test_pixel_head_restatement():
+    """§8(f) row 2: the rearrangement of the pixel head against einops' own pattern, the pixel terms against torch's losses."""
+    from einops import rearrange
+    g = torch.Generator().manual_seed(0)
+    B, gh, gw, p = 3, 4, 5, 7
+    pt = torch.randn(B * gh * gw, p * p * 3, generator=g)
+    want = rearrange(pt.reshape(B, gh * gw, p * p * 3), "n (h w) (p q c) -> n c (h p) (w q)", h=gh, w=gw, p=p, q=p, c=3)
+    assert torch.equal(O.unpatchify(pt, B, gh, gw, p), want)
+    a, b = torch.randn(B, 3, 28, 35, generator=g), torch.randn(B, 3, 28, 35, generator=g)
+    assert torch.allclose(O.pixel_loss(a, b, "mse"), torch.nn.functional.mse_loss(a, b), rtol=1e-6)
+    assert torch.allclose(O.pixel_loss(a, b, "l1"), torch.nn.functional.l1_loss(a, b), rtol=1e-6)

@@ -170,3 +170,41 @@ def test_lm_loss_restatement_vs_reference_statements_live():
     for seed, B, T, V, padding in ((0, 2, 9, 37, "none"), (5, 4, 17, 101, "right"), (6, 3, 13, 64, "left")):
         logits, labels, am = O.lm_loss_inputs(seed, B, T, V, padding)
         assert torch.equal(R.rac_lm_loss(logits, labels, am), O.lm_loss(logits, labels, am))
+
+
+def test_pixel_terms_equal_the_reference_losses():
+    """§8(f) row 2: the oracle's pixel terms against the reference's own WeightedMSELoss module (loss/mse.py, loaded by file path) and the
+    statements of the GAN loss's pixel term (loss/discriminator.py:161,170: torch.abs(inputs - reconstructions), torch.mean)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rac_mse", os.path.join(R.REF_ROOT, "src", "model", "loss", "mse.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(4, 3, 28, 42, generator=g), torch.randn(4, 3, 28, 42, generator=g)
+    assert torch.equal(O.pixel_loss(a, b, "mse"), mod.WeightedMSELoss()(a, b))
+    assert torch.equal(O.pixel_loss(a, b, "l1"), torch.mean(torch.abs(b.contiguous() - a.contiguous())))
+
+
+def test_stage2_oracle_projector_and_splice_match_the_reference_autograd():
+    """The stage-2 golden (tests/golden/stage2.npz) is generated by rac_stage2_grads; here the same quantities come from the ORACLE's projector +
+    splice under torch autograd, live against the reference's modules: equal loss and gradients (fp32 rounding)."""
+    Bm = R.load_reference_projector_builder()
+    seed, B, T, V, Dt, Dh = 21, 4, 11, 30, 48, 32
+    ids, am, labels, feats, W = O.splice_inputs(seed, B, T, V, Dh)
+    g = torch.Generator().manual_seed(seed)
+    toks = [torch.randn(f.shape[0], Dt, generator=g) for f in feats]
+    w_down = torch.randn(V, Dh, generator=g) * 0.3
+    torch.manual_seed(seed)
+    proj = Bm.build_vision_projector("mlp2x_gelu", mm_hidden_size=Dt, hidden_size=Dh)
+    pos = torch.arange(T).expand(B, T).clone()
+    loss, embeds, new_labels, pg, tg, _ = R.rac_stage2_grads(proj, toks, ids, pos, am, labels, W, w_down)
+    psd = {n: p.detach().clone().requires_grad_(True) for n, p in proj.named_parameters()}
+    tl = [t.clone().requires_grad_(True) for t in toks]
+    of = [O.projector_forward(psd, "mlp2x_gelu", t) for t in tl]
+    _, _, oemb, olab = O.splice_multimodal(ids, pos, am, labels, of, W)
+    ol = O.stage2_downstream(oemb, olab, w_down)
+    ol.backward()
+    assert torch.equal(olab, new_labels) and torch.allclose(oemb, embeds, rtol=1e-6, atol=1e-6) and torch.allclose(ol, loss, rtol=1e-6)
+    for n in pg:
+        assert torch.allclose(psd[n].grad, pg[n], rtol=1e-4, atol=1e-6), n
+    for a, b in zip(tl, tg):
+        assert torch.allclose(a.grad if a.grad is not None else torch.zeros_like(a), b, rtol=1e-4, atol=1e-6)
