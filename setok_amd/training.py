@@ -344,10 +344,11 @@ class HeadTrainer:
         for p in self.params.values():
             torch.autograd.graph.increment_version(p)                 # what an in-place torch op would have done: every version-keyed cache notices
         self.tok.__dict__["_ctx"] = None
-        for m in self.tok.modules():
-            m.__dict__.pop("_f32_cache", None)
-            if hasattr(m, "_drop_pack"):
-                m._drop_pack()
+        for top in HEAD_MODULES:                                      # (not the frozen tower: its fused / folded copies stay valid)
+            for m in getattr(self.tok, top).modules():
+                m.__dict__.pop("_f32_cache", None)
+                if hasattr(m, "_drop_pack"):
+                    m._drop_pack()
 
     def comm_stats(self) -> Dict[str, float]:
         """Of the last step(s): gradient bytes all-reduced per step and the exposed (not overlapped with the backward pass) all-reduce time —

@@ -314,6 +314,45 @@ def gen_head_grads():
 
 
 # ----------------------------------------------------------------------------------------------
+def gen_bf16_reference():
+    """The bf16 throughput mode's yardstick: the REFERENCE's own head cast to torch.bfloat16 (what train_setokim.py:326 does to the whole tower
+    module) run on CPU from fixed bf16 features — the reference's fp32 tower features of vitl_224.npz / vitl_336.npz rounded to bf16 — and, per
+    stage, its distance from the fp32 oracle evaluated on the SAME bf16-valued inputs (x after the positional add, the bf16-rounded weights) and the
+    SAME cluster assignment.  A GPU bf16 result is held to <= 1.5 x these distances (tests/test_fullsize_gpu.py).  Stored per image: the
+    reference-bf16 assignment and token count, the three stage errors, the tokens themselves, and what the fp32 clustering yields on the same
+    features (the reference's bf16 clustering rounds its scores to bf16 and may pick a different L)."""
+    hc = O.HeadConfig(threshold=0.125)
+    hsd = O.init_head_weights(hc, seed=1)
+    hsd_b = {k: v.bfloat16().float() for k, v in hsd.items()}
+    d = R.make_clip_dir(1024, 1, 16, 4096, 224, 14, seed=0)            # a 1-layer stand-in tower: only the head is exercised
+    tok = R.build_reference_tokenizer(d, hidden_dim=1024, token_feat_dim=4096, dim_feedforward=4096, min_cluster_num=64, threshold=0.125,
+                                      select_layer=-2)
+    res = tok.load_state_dict(hsd, strict=False)
+    assert not res.unexpected_keys
+    tok = tok.to(torch.bfloat16)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    arrs = {}
+    for cfg, src in (("cfg2", "vitl_224"), ("cfg4", "vitl_336")):
+        feats = torch.from_numpy(np.load(os.path.join(HERE, src + ".npz"))["feats"])
+        for i in range(feats.shape[0]):
+            r = R.rac_head_single(tok, feats[i].bfloat16(), return_stages=True)
+            x, lab = r["x"].float(), r["idx_cluster"]
+            group = O.group_encoding(hsd_b, hc, x, lab)
+            inter = O.block_forward(hsd_b, "inter_encoder.", group, hc.nheads, hc.intra_cluster_layers)
+            tokens = torch.nn.functional.linear(inter, hsd_b["out.weight"], hsd_b["out.bias"])
+            errs = [rel(r["group"].float(), group), rel(r["inter"].float(), inter), rel(r["tokens"].float(), tokens)]
+            f32 = O.cluster_dpc_knn(x, hc.min_cluster_num, hc.threshold, hc.min_cluster_num)
+            pre = f"{cfg}:{i}:"
+            arrs[pre + "idx_cluster"] = npy(lab).astype(np.int32)
+            arrs[pre + "errs"] = np.array(errs)
+            arrs[pre + "L"] = np.array([r["tokens"].shape[0], f32.index_down.numel()])
+            if cfg == "cfg2":
+                arrs[pre + "tokens"] = npy(r["tokens"].float())
+            print(f"  {cfg}/img{i}: reference-bf16 L = {r['tokens'].shape[0]} (fp32 clustering of the same features: {f32.index_down.numel()}); "
+                  f"reference-bf16 vs fp32 oracle: group {errs[0]:.3e} inter {errs[1]:.3e} tokens {errs[2]:.3e}")
+    save("bf16_reference", **arrs)
+
+
 STAGE2_CASES = {
     # name: (projector_type, seed, B, T, V, token_feat_dim, hidden, kwargs, train_embed)
     "mlp2x": ("mlp2x_gelu", 11, 5, 12, 40, 96, 64, dict(), False),
@@ -452,6 +491,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["head_small", "cluster_full", "e2e_small", "vitl", "detok", "splice", "head_grads", "llama", "lm_loss", "stage2"]
     if "stage2" in which:
         gen_stage2()
+    if "bf16_reference" in which:
+        gen_bf16_reference()
     if "detok" in which:
         gen_detok()
     if "splice" in which:

@@ -93,6 +93,50 @@ def _own_features_contract(tok, st, idx, toks, grid, n_images, sd_head, hc, ulps
 
 
 # ======================================================================================================================================
+# the bf16 mode against the REFERENCE'S OWN bf16 run (tests/golden/bf16_reference.npz: the reference's head cast to torch.bfloat16, as
+# train_setokim.py:326 casts the module, run on CPU from fixed bf16 features)
+# ======================================================================================================================================
+BF16_VS_REFERENCE = 1.5    # a GPU stage may be at most this factor further from the fp32 oracle than the reference's own bf16 arithmetic is
+
+
+@pytest.mark.parametrize("cfg,src,grid", [("cfg2", "vitl_224", 16), ("cfg4", "vitl_336", 24)])
+def test_bf16_mode_is_no_worse_than_the_references_own_bf16_run(golden_dir, cfg, src, grid):
+    """Per stage (group, inter, tokens): |GPU bf16 - fp32 oracle| <= 1.5 x |reference bf16 - fp32 oracle|, each measured on ITS OWN bf16-valued
+    features x and ITS OWN cluster assignment (the reference's bf16 clustering rounds the scores to bf16 and picks a slightly different L than the
+    fp32 clustering of the same features, which is what the GPU computes: 37 / 46 against 36 / 47 at cfg2), with the bf16-rounded weights.
+    The measured errors are printed (-s) and recorded in DESIGN.md §2."""
+    z = np.load(os.path.join(golden_dir, "bf16_reference.npz"))
+    feats = _t(np.load(os.path.join(golden_dir, src + ".npz"))["feats"])
+    hc = O.HeadConfig(threshold=0.125)
+    sd_head = {k: v.bfloat16().float() for k, v in O.init_head_weights(hc, seed=1).items()}
+    tok = _vitl_tok(img=14 * grid, dtype=torch.bfloat16, with_tower=False)
+    B, N = feats.shape[0], grid * grid
+    hidden = torch.cat([torch.cat([torch.zeros(1, 1024), f], 0) for f in feats], 0).to(DEV, torch.bfloat16)      # class-token rows that 'patch' drops
+    toks, idx, score, st = tok.encode_features(hidden, B, return_stages=True)
+    x = st["x"].float().cpu().reshape(B, N, -1)
+    offs = np.concatenate([[0], np.cumsum(st["counts"])])
+    worst = dict(group=(0.0, 0.0), inter=(0.0, 0.0), tokens=(0.0, 0.0))
+    for i in range(B):
+        lab = idx[i].cpu()
+        group = O.group_encoding(sd_head, hc, x[i], lab)
+        inter = O.block_forward(sd_head, "inter_encoder.", group, hc.nheads, hc.intra_cluster_layers)
+        tokens = torch.nn.functional.linear(inter, sd_head["out.weight"], sd_head["out.bias"])
+        mine = dict(group=_rel(st["group"][offs[i]: offs[i + 1]].float(), group), inter=_rel(st["inter"][offs[i]: offs[i + 1]].float(), inter),
+                    tokens=_rel(toks[i].float(), tokens))
+        ref = dict(zip(("group", "inter", "tokens"), z[f"{cfg}:{i}:errs"].tolist()))
+        f32_L = int(z[f"{cfg}:{i}:L"][1])
+        assert st["counts"][i] == f32_L, (st["counts"][i], f32_L)                       # the GPU's L == the fp32 clustering of the same bf16 features
+        print(f"{cfg} image {i}: L = {st['counts'][i]} (reference bf16: {int(z[f'{cfg}:{i}:L'][0])});  " +
+              "  ".join(f"{k}: gpu {mine[k]:.3e} / reference-bf16 {ref[k]:.3e}" for k in mine))
+        for k in mine:
+            assert mine[k] <= BF16_VS_REFERENCE * ref[k], (cfg, i, k, mine[k], ref[k])
+            assert mine[k] < BF16_TOKEN_TOL
+            if mine[k] / ref[k] > worst[k][0] / max(worst[k][1], 1e-30):
+                worst[k] = (mine[k], ref[k])
+    print(f"{cfg} worst ratios:", {k: round(a / b, 3) for k, (a, b) in worst.items()})
+
+
+# ======================================================================================================================================
 # cfg2 — the bf16 mode's contract at ViT-L/14-224 dims
 # ======================================================================================================================================
 def test_cfg2_bf16_contract_on_the_gpus_own_features():
