@@ -13,7 +13,7 @@
  *   - every pointer is a DEVICE pointer (HBM) unless the name ends in `_host`;
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates
  *     nothing, and synchronises nothing — outputs and workspaces are caller-allocated (the context
- *     entry points are the documented exception: they own the weights and read back the token counts);
+ *     entry points are the documented exception: they own the weights; setok_encode synchronises only on request);
  *   - `dtype` selects the activation/weight element type: SETOK_F32 (parity mode; fp32 MFMA,
  *     exact fma chains) or SETOK_BF16 (throughput mode; bf16 MFMA, fp32 accumulation);
  *     biases, LayerNorm affine parameters, scores and distances are always fp32;
@@ -54,9 +54,9 @@ int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* 
  * `SetokTokenizer.forward` (src/model/setok/tokenizer.py:157-182): tower (clip_encoder.py:50-62, HF CLIP ViT hidden_states[select_layer],
  * feature_select :40-48) -> + PositionalEncoding2D (:164-168) -> cluster_dpc_knn (:174) -> group_encoding (:177-178) -> inter_encoder
  * (:179) -> out (:180).  A context owns device copies of the weights in compute layout; setok_encode runs the path on the caller's
- * stream into caller-allocated buffers.  These are the only entry points that allocate (create / load / ready) or synchronise:
- * setok_encode waits ONCE for the stream, after the clustering, to read the B per-image token counts that size the ragged stages
- * (the same single host read the reference's data-dependent shapes force on any implementation).
+ * stream into caller-allocated buffers.  These are the only entry points that allocate (create / load / ready); setok_encode itself is
+ * asynchronous: the data-dependent shapes of the ragged stages (per-image token counts) are read on the DEVICE, the host reads them after the
+ * call when it wants them (see below).
  * Contexts are independent: no global mutable state, one context per (device, stream) in use at a time. */
 typedef struct setok_ctx setok_ctx;
 
@@ -92,10 +92,15 @@ int setok_weights_ready(setok_ctx* ctx, void* stream);
 int64_t setok_encode_workspace_bytes(const setok_ctx* ctx, int B);
 
 /* images (B, 3, image_size, image_size) in the compute dtype -> tokens: packed (sum_b L_b, token_feat_dim) rows, image b owning rows
- * [sum_{b' < b} L_b', + L_b) (capacity B * N rows), counts (B) int32 on the device and in `counts_host`, idx_cluster (B, N) int64,
- * score (B, N) fp32, index_down (B, N) int64 (-1 padded).  k / threshold == 0 select the configured defaults (the reference's
+ * [sum_{b' < b} L_b', + L_b) (capacity B * N rows; rows past sum_b L_b are never written), counts (B) int32 on the device, idx_cluster (B, N)
+ * int64, score (B, N) fp32, index_down (B, N) int64 (-1 padded).  k / threshold == 0 select the configured defaults (the reference's
  * truthiness rule, tokenizer.py:171-172); noise / token_mask as in setok_cluster_dpc_knn (NULL = none).  The optional stage_* outputs
- * receive pointers INTO the workspace (valid until its next use): x = features + positions (B*N, C), group (sum L, C), inter (sum L, C). */
+ * receive pointers INTO the workspace (valid until its next use): x = features + positions (B*N, C), group (sum L, C), inter (sum L, C).
+ *
+ * ASYNCHRONOUS (since ABI 5): no host synchronisation between the stages — the ragged stages are launched at their worst-case
+ * size and read the per-image token counts on the device — so with counts_host == NULL the call only enqueues work on `stream` (it can be
+ * captured into a hipGraph) and the host reads `counts` whenever it needs shapes.  counts_host != NULL (B ints; total_tokens_host optional) is
+ * the convenience form: ONE stream synchronisation at the END of the call fills them. */
 int setok_encode(setok_ctx* ctx, void* stream, const void* images, int B, int k, float threshold, const float* noise,
                  const float* token_mask, void* workspace, int64_t workspace_bytes, void* tokens, int32_t* counts,
                  int64_t* idx_cluster, float* score, int64_t* index_down, int32_t* counts_host, int64_t* total_tokens_host,

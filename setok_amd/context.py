@@ -41,6 +41,7 @@ class EncodeContext:
         _lib.call("setok_create", C.byref(sc), C.byref(self.handle))
         self.device, self.dtype = dev, dt
         self.N = (cfg.image_size // cfg.patch_size) ** 2
+        self.image_size = cfg.image_size
         self.C, self.D = cfg.hidden_size, tok.token_feat_dim
         self._ws = {}
         st = _stream()
@@ -72,9 +73,14 @@ class EncodeContext:
             pass
 
     def encode(self, images: torch.Tensor, k: Optional[int] = None, threshold: Optional[float] = None, noise=None, token_mask=None,
-               return_stages: bool = False):
+               return_stages: bool = False, sync: bool = True):
         """images (B, 3, H, W) on the context's device -> (packed tokens (sum L_i, D), counts list, idx_cluster (B, N) int64,
-        score (B, N) fp32, index_down (B, N) int64[, stages])."""
+        score (B, N) fp32, index_down (B, N) int64[, stages]).
+
+        `setok_encode` itself never waits for the device (the ragged stages read the token counts there); this wrapper reads the B counts
+        ONCE, after everything is queued, because a RaggedTokens needs host-side shapes.  sync=False skips even that: the call only enqueues
+        work (it can be captured into a graph) and returns (tokens at the worst-case capacity (B * N, D), counts as a DEVICE int32 tensor, idx,
+        score, index_down); rows of `tokens` past sum(counts) are unspecified."""
         B, N, dev = images.shape[0], self.N, self.device
         x = images.to(device=dev, dtype=self.dtype).contiguous()
         nbytes = _lib.load().setok_encode_workspace_bytes(self.handle, B)
@@ -93,14 +99,18 @@ class EncodeContext:
         if token_mask is not None:
             token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
             assert token_mask.numel() == B * N
-        counts_h = (C.c_int32 * B)()
+        counts_h = (C.c_int32 * B)() if sync else None
         total = C.c_int64(0)
         sx, sg, si = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _lib.call("setok_encode", self.handle, _stream(), x.data_ptr(), B, int(k) if k else 0, float(threshold) if threshold else 0.0,
                   None if noise is None else noise.data_ptr(), None if token_mask is None else token_mask.data_ptr(),
                   ws.data_ptr(), ws.numel(), tokens.data_ptr(), counts.data_ptr(), idx.data_ptr(), score.data_ptr(), index_down.data_ptr(),
-                  counts_h, C.byref(total), C.byref(sx) if return_stages else None, C.byref(sg) if return_stages else None,
+                  counts_h, C.byref(total) if sync else None, C.byref(sx) if return_stages else None, C.byref(sg) if return_stages else None,
                   C.byref(si) if return_stages else None)
+        if not sync:
+            if return_stages:
+                raise ValueError("return_stages needs the host-side counts (sync=True)")
+            return tokens, counts, idx, score, index_down
         cl = list(counts_h)
         out = (tokens[: total.value], cl, idx, score, index_down)
         if not return_stages:
@@ -111,3 +121,30 @@ class EncodeContext:
             off = ptr.value - ws.data_ptr()
             return ws[off: off + rows * self.C * es].view(self.dtype).reshape(rows, self.C).clone()
         return out + (dict(x=view(sx, B * N), group=view(sg, total.value), inter=view(si, total.value), index_down=index_down, counts=cl),)
+
+
+class GraphedEncode:
+    """The latency form of the path for small, repeated batches (the reference's dataset side encodes ONE image per call from DataLoader workers,
+    src/dataset/pairDataset.py:419-421): `setok_encode` is free of host synchronisation, so a whole call — ~200 kernel launches at ViT-L — is
+    captured ONCE per batch size into a HIP graph on static buffers and replayed; per call the host then pays one graph launch, one copy of the
+    images into the static input and one read of the B token counts.  Bit-identical to the eager call (the same kernels on the same data)."""
+
+    def __init__(self, ctx: "EncodeContext", B: int, k: Optional[int] = None, threshold: Optional[float] = None):
+        self.ctx, self.B = ctx, B
+        cfg_side = int(round((ctx.N) ** 0.5))
+        self.images = torch.zeros((B, 3, ctx.image_size, ctx.image_size), dtype=ctx.dtype, device=ctx.device)
+        ctx.encode(self.images, k, threshold, sync=False)                              # warm-up: one-time attribute calls must not land in the capture
+        torch.cuda.synchronize(ctx.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = ctx.encode(self.images, k, threshold, sync=False)
+        self._ws = ctx._ws                                                             # the captured launches point into this workspace: keep it alive
+
+    def __call__(self, images: torch.Tensor):
+        """-> (packed tokens (sum L_i, D) — a fresh tensor —, counts list, idx_cluster, score, index_down) like EncodeContext.encode."""
+        assert tuple(images.shape) == tuple(self.images.shape)
+        self.images.copy_(images, non_blocking=True)
+        self.graph.replay()
+        tokens, counts, idx, score, index_down = self.out
+        cl = counts.cpu().tolist()                                                      # the one synchronisation, after the replay was queued
+        return tokens[: sum(cl)].clone(), cl, idx.clone(), score.clone(), index_down.clone()

@@ -920,7 +920,9 @@ __global__ __launch_bounds__(256) void sort_kernel(const int64_t* __restrict__ i
     }
     const int base = img_offsets[b];
     for (int c = tid; c < L; c += 256) seg_offsets[base + c] = b * N + start[c];
-    if (b == B - 1 && tid == 0) seg_offsets[base + L] = B * N;
+    // the entries after the last cluster's: every one = B * N, i.e. the segments [total, B * N) are EMPTY — a consumer that does not know the
+    // number of clusters (setok_encode: no host read of the counts) launches for B * N segments and the surplus ones exit at once
+    if (b == B - 1) for (int i = base + L + tid; i <= B * N; i += 256) seg_offsets[i] = B * N;
 }
 
 extern "C" int setok_cluster_sort(void* stream, const int64_t* idx_cluster, const int32_t* counts, int B, int N,

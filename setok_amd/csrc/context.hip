@@ -261,6 +261,10 @@ extern "C" int setok_weights_ready(setok_ctx* c, void* stream) {
     return SETOK_OK;
 }
 
+// (C++ linkage: the forms with a device-side row count, gemm.hip / norm_attn.hip)
+int setok_linear_dev(void*, int, int, const void*, int64_t, const void*, const float*, const void*, void*, int64_t, int, int, int, int, int, int64_t, int64_t, int64_t, const int32_t*);
+int setok_layernorm_dev(void*, int, const void*, const float*, const float*, void*, int, int, float, const int32_t*);
+
 // ---- workspace ------------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -318,6 +322,7 @@ Plan plan(const setok_ctx* c, int B, char* base) {
 
 extern "C" {
 int setok_linear(void*, int, int, const void*, int64_t, const void*, const float*, const void*, void*, int64_t, int, int, int, int, int, int64_t, int64_t, int64_t);
+
 int setok_linear_ln(void*, const void*, int64_t, const void*, const float*, const float*, void*, int64_t, int, int, int, int);
 int setok_row_stats(void*, int, const void*, float*, int, int, float);
 int setok_layernorm(void*, int, const void*, const float*, const float*, void*, int, int, float);
@@ -333,25 +338,26 @@ int setok_segment_mean(void*, int, const void*, const int32_t*, const int32_t*, 
 
 #define RUN(call) do { const int rc__ = (call); if (rc__ != SETOK_OK) return rc__; } while (0)
 
-int lin(void* st, int dt, const void* a, int K, const void* w, const float* b, const void* res, void* out, int M, int N, int act) {
-    return setok_linear(st, dt, dt, a, K, w, b, res, out, N, M, N, K, act, 1, 0, 0, 0);
+int lin(void* st, int dt, const void* a, int K, const void* w, const float* b, const void* res, void* out, int M, int N, int act, const int32_t* m_dev = nullptr) {
+    return setok_linear_dev(st, dt, dt, a, K, w, b, res, out, N, M, N, K, act, 1, 0, 0, 0, m_dev);
 }
 
-// Block.forward (module.py:95-100) on packed rows, each row attending within its own segment; h is updated in place.
+// Block.forward (module.py:95-100) on packed rows, each row attending within its own segment; h is updated in place.  `rows` sizes the launches;
+// `rows_dev` (optional, device) is the number of rows that exist: the ragged stages run without the host knowing it.
 int block_rows(const setok_ctx* c, void* st, const BlockW& b, void* h, int rows, const int32_t* seg_offsets, int n_segs, int seg_bound,
-               void* y, void* qkv, void* o, void* u) {
+               void* y, void* qkv, void* o, void* u, const int32_t* rows_dev = nullptr) {
     const setok_config& f = c->cfg;
     const int C = f.hidden_size, H = f.nheads, Dh = C / H, dt = f.dtype;
     const float eps = 1e-5f, scale = 1.0f / sqrtf((float)Dh);                       // nn.LayerNorm default eps; qk_scale None -> head_dim ** -0.5 (module.py:54)
     for (const auto& a : b.attn) {
-        RUN(setok_layernorm(st, dt, h, b.n1w, b.n1b, y, rows, C, eps));
-        RUN(lin(st, dt, y, C, a.wqkv, a.bqkv, nullptr, qkv, rows, 3 * C, SETOK_ACT_NONE));
+        RUN(setok_layernorm_dev(st, dt, h, b.n1w, b.n1b, y, rows, C, eps, rows_dev));
+        RUN(lin(st, dt, y, C, a.wqkv, a.bqkv, nullptr, qkv, rows, 3 * C, SETOK_ACT_NONE, rows_dev));
         RUN(setok_attention(st, dt, qkv, seg_offsets, n_segs, seg_bound, o, rows, H, Dh, scale));
-        RUN(lin(st, dt, o, C, a.wproj, a.bproj, h, h, rows, C, SETOK_ACT_NONE));
+        RUN(lin(st, dt, o, C, a.wproj, a.bproj, h, h, rows, C, SETOK_ACT_NONE, rows_dev));
     }
-    RUN(setok_layernorm(st, dt, h, b.n2w, b.n2b, y, rows, C, eps));
-    RUN(lin(st, dt, y, C, b.w1, b.b1, nullptr, u, rows, f.dim_feedforward, SETOK_ACT_GELU_ERF));
-    RUN(lin(st, dt, u, f.dim_feedforward, b.w2, b.b2, h, h, rows, C, SETOK_ACT_NONE));
+    RUN(setok_layernorm_dev(st, dt, h, b.n2w, b.n2b, y, rows, C, eps, rows_dev));
+    RUN(lin(st, dt, y, C, b.w1, b.b1, nullptr, u, rows, f.dim_feedforward, SETOK_ACT_GELU_ERF, rows_dev));
+    RUN(lin(st, dt, u, f.dim_feedforward, b.w2, b.b2, h, h, rows, C, SETOK_ACT_NONE, rows_dev));
     return SETOK_OK;
 }
 
@@ -366,7 +372,7 @@ extern "C" int setok_encode(setok_ctx* c, void* stream, const void* images, int 
                             const float* token_mask, void* workspace, int64_t workspace_bytes, void* tokens, int32_t* counts,
                             int64_t* idx_cluster, float* score, int64_t* index_down, int32_t* counts_host, int64_t* total_tokens_host,
                             void** stage_x, void** stage_group, void** stage_inter) {
-    SETOK_CHECK_ARG(c && images && workspace && tokens && counts && idx_cluster && score && index_down && counts_host, "setok_encode: null argument");
+    SETOK_CHECK_ARG(c && images && workspace && tokens && counts && idx_cluster && score && index_down, "setok_encode: null argument");
     SETOK_CHECK_ARG(B > 0, "setok_encode: B=%d", B);
     if (!c->ready) return ctx_fail(c, SETOK_EINVAL, "setok_encode: call setok_weights_ready after loading the weights");
     const setok_config& f = c->cfg;
@@ -415,7 +421,28 @@ extern "C" int setok_encode(setok_ctx* c, void* stream, const void* images, int 
     const int kk = k != 0 ? k : f.min_cluster_num;                                    // `k if k else self.min_cluster_num` (:172)
     RUN(setok_cluster_dpc_knn(st, dt, p.x, B, N, C, kk, thr, f.min_cluster_num, noise, token_mask, idx_cluster, score, index_down, counts, p.dist_ws, p.vec_ws));
     RUN(setok_cluster_sort(st, idx_cluster, counts, B, N, p.perm, p.seg_offsets, p.img_offsets));
-    // the one host synchronisation: L_i sizes the ragged stages
+    // No host synchronisation between the stages: the ragged stages are launched at their worst-case size — B * N cluster
+    // segments, B * N cluster-token rows — and take the actual numbers from the device: the segment offsets past the last cluster are empty
+    // segments (setok_cluster_sort), the GEMMs / LayerNorms of the inter encoder and `out` read the row count sum(L_i) = img_offsets[B] and skip
+    // everything beyond it.  Rows [sum L_i, B * N) of `tokens` are never written.
+    const int rN = B * N;
+    const int32_t* total_dev = p.img_offsets + B;
+    RUN(setok_gather_rows(st, dt, p.x, p.perm, p.hs, rN, C));                                                                // x[m] for every cluster (:150)
+    RUN(block_rows(c, st, c->inner, p.hs, rN, p.seg_offsets, rN, N, p.y2, p.qkv2, p.o2, p.u2));                              // inner_encoder (:150)
+    RUN(setok_segment_mean(st, dt, p.hs, p.seg_offsets, total_dev, rN, p.group, C));                                         // mean over members (:151-153)
+    if (stage_x) *stage_x = p.x;
+    void* inter = p.group;
+    if (stage_group) {                                                                                                       // keep the group stage: run inter_encoder on a copy
+        if (hipMemcpyAsync(p.o2, p.group, (size_t)rN * C * elem_size(dt), hipMemcpyDeviceToDevice, s) != hipSuccess) return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: copy failed");
+        *stage_group = p.group;
+        inter = p.hs;                                                                                                        // hs is dead now
+        if (hipMemcpyAsync(inter, p.o2, (size_t)rN * C * elem_size(dt), hipMemcpyDeviceToDevice, s) != hipSuccess) return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: copy failed");
+    }
+    RUN(block_rows(c, st, c->inter, inter, rN, p.img_offsets, B, N, p.y2, p.qkv2, p.o2, p.u2, total_dev));                    // inter_encoder (:179, +D2)
+    if (stage_inter) *stage_inter = inter;
+    RUN(lin(st, dt, inter, C, W("out.weight"), (const float*)W("out.bias"), nullptr, tokens, rN, f.token_feat_dim, SETOK_ACT_NONE, total_dev));   // :180
+    if (!counts_host) return SETOK_OK;                                                // fully asynchronous: the caller reads `counts` when it wants shapes
+    // convenience for hosts that want the shapes right away: ONE synchronisation, at the END of the call (every launch is already queued)
     if (c->counts_cap < B) {
         if (c->counts_pinned) (void)hipHostFree(c->counts_pinned);
         c->counts_pinned = nullptr; c->counts_cap = 0;
@@ -424,22 +451,8 @@ extern "C" int setok_encode(setok_ctx* c, void* stream, const void* images, int 
     }
     if (hipMemcpyAsync(c->counts_pinned, counts, (size_t)B * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: reading the token counts failed: %s", hipGetErrorString(hipGetLastError()));
-    int64_t total = 0; int maxL = 0;
-    for (int b = 0; b < B; ++b) { counts_host[b] = c->counts_pinned[b]; total += counts_host[b]; if (counts_host[b] > maxL) maxL = counts_host[b]; }
+    int64_t total = 0;
+    for (int b = 0; b < B; ++b) { counts_host[b] = c->counts_pinned[b]; total += counts_host[b]; }
     if (total_tokens_host) *total_tokens_host = total;
-    RUN(setok_gather_rows(st, dt, p.x, p.perm, p.hs, B * N, C));                                                             // x[m] for every cluster (:150)
-    RUN(block_rows(c, st, c->inner, p.hs, B * N, p.seg_offsets, (int)total, N, p.y2, p.qkv2, p.o2, p.u2));                   // inner_encoder (:150)
-    RUN(setok_segment_mean(st, dt, p.hs, p.seg_offsets, p.img_offsets + B, (int)total, p.group, C));                         // mean over members (:151-153)
-    if (stage_x) *stage_x = p.x;
-    void* inter = p.group;
-    if (stage_group) {                                                                                                       // keep the group stage: run inter_encoder on a copy
-        if (hipMemcpyAsync(p.o2, p.group, (size_t)total * C * elem_size(dt), hipMemcpyDeviceToDevice, s) != hipSuccess) return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: copy failed");
-        *stage_group = p.group;
-        inter = p.hs;                                                                                                        // hs is dead now
-        if (hipMemcpyAsync(inter, p.o2, (size_t)total * C * elem_size(dt), hipMemcpyDeviceToDevice, s) != hipSuccess) return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: copy failed");
-    }
-    RUN(block_rows(c, st, c->inter, inter, (int)total, p.img_offsets, B, maxL, p.y2, p.qkv2, p.o2, p.u2));                   // inter_encoder (:179, +D2)
-    if (stage_inter) *stage_inter = inter;
-    RUN(lin(st, dt, inter, C, W("out.weight"), (const float*)W("out.bias"), nullptr, tokens, (int)total, f.token_feat_dim, SETOK_ACT_NONE));   // :180
     return SETOK_OK;
 }

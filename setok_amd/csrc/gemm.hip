@@ -25,7 +25,9 @@ struct GemmArgs {
     const void* A; const void* W; const float* bias; const void* res; void* C;
     int64_t lda, ldc, sA, sW, sC;
     int M, N, K, act;
+    const int32_t* m_dev;        // optional DEVICE-side row count (<= M): rows beyond it are neither read nor written (setok_encode's ragged stages)
 };
+__device__ inline int rows_of(const GemmArgs& g) { return g.m_dev ? min(g.M, *g.m_dev) : g.M; }
 
 template <typename TO> __device__ inline float ld_out(const TO* p) { return Elem<TO>::ld(p); }
 template <typename TO> __device__ inline float round_to(float v) { return (float)(TO)v; }
@@ -47,6 +49,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int Mrt = rows_of(g);
+    if (m0 >= Mrt) return;                                               // (whole workgroup: before any barrier)
     const bf16* A = (const bf16*)g.A + (int64_t)blockIdx.z * g.sA;
     const bf16* W = (const bf16*)g.W + (int64_t)blockIdx.z * g.sW;
     TO* C = (TO*)g.C + (int64_t)blockIdx.z * g.sC;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int c = tid + 256 * p, row = c >> 3, kc = c & 7;
-        const int ar = min(m0 + row, g.M - 1), br = min(n0 + row, g.N - 1);
+        const int ar = min(m0 + row, max(Mrt - 1, 0)), br = min(n0 + row, g.N - 1);
         a_src[p] = A + (int64_t)ar * g.lda + kc * 8;
         b_src[p] = W + (int64_t)br * g.K + kc * 8;
         st_off[p] = lds_off_bf16(row, kc);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
+                if (row >= Mrt) continue;
                 float v = acc[i][j][r];
                 if (g.act == SETOK_ACT_QUICK_GELU) v = FAST_ACT ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * v)) : v / (1.0f + expf(-1.702f * v));
                 else if (g.act == SETOK_ACT_GELU_ERF) v = FAST_ACT ? gelu_erf_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -145,9 +149,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                            bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum);    // gemm_persist.hip
+                            bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev);    // gemm_persist.hip
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                          bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum);      // gemm_persist.hip
+                          bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev);      // gemm_persist.hip
 int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, float* C, int64_t ldc, int M, int N, int K, int batch,
                                    int64_t sA, int64_t sW, int64_t sC);               // gemm_persist.hip
 
@@ -162,13 +166,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * FM, n0 = blockIdx.x * FN;
+    const int Mrt = rows_of(g);
+    if (m0 >= Mrt) return;
     const float* A = (const float*)g.A + (int64_t)blockIdx.z * g.sA;
     const float* W = (const float*)g.W + (int64_t)blockIdx.z * g.sW;
     float* C = (float*)g.C + (int64_t)blockIdx.z * g.sC;
     const float* R = g.res ? (const float*)g.res + (int64_t)blockIdx.z * g.sC : nullptr;
 
     const int srow = tid >> 2, skq = tid & 3;
-    const float* a_src = A + (int64_t)min(m0 + srow, g.M - 1) * g.lda + skq * 4;
+    const float* a_src = A + (int64_t)min(m0 + srow, max(Mrt - 1, 0)) * g.lda + skq * 4;
     const float* b_src = W + (int64_t)min(n0 + srow, g.N - 1) * g.K + skq * 4;
 
     // Blocked summation: each 64-deep K chunk is an exact fma chain from zero, chunks are then added —
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
+        if (row >= Mrt) continue;
         float v = acc[r] + bv;
         if (g.act == SETOK_ACT_QUICK_GELU) v = v / (1.0f + expf(-1.702f * v));
         else if (g.act == SETOK_ACT_GELU_ERF) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -231,15 +237,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // --------------------------------------------------------------------------------------------
 static bool g_force_small_tiles = false;   // test hook: SETOK_GEMM_SMALL_TILES=1 keeps every bf16 GEMM on the 128x128 kernel
 
-extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* A, int64_t lda, const void* W,
-                            const float* bias, const void* residual, void* C, int64_t ldc, int M, int N, int K,
-                            int act, int batch, int64_t strideA, int64_t strideW, int64_t strideC) {
+// setok_linear with an optional DEVICE-side row count `m_dev` (one int32, <= M): the launch is sized for M rows, tiles beyond *m_dev exit at once
+// and no row beyond it is read or written — how setok_encode runs its ragged stages (the rows of all images' cluster tokens) without the host
+// knowing their number.  The kernel is chosen from M exactly as without m_dev, and all bf16 kernels share their arithmetic per output row, so
+// the results do not depend on it.
+int setok_linear_dev(void* stream, int dtype, int out_dtype, const void* A, int64_t lda, const void* W,
+                     const float* bias, const void* residual, void* C, int64_t ldc, int M, int N, int K,
+                     int act, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const int32_t* m_dev) {
     SETOK_CHECK_ARG(A && W && C, "setok_linear: null operand");
     SETOK_CHECK_ARG(M >= 0 && N > 0 && K > 0 && batch >= 1, "setok_linear: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     SETOK_CHECK_ARG(act >= SETOK_ACT_NONE && act <= SETOK_ACT_GELU_ERF, "setok_linear: bad act %d", act);
     SETOK_CHECK_ARG(lda >= K && ldc >= N, "setok_linear: lda/ldc too small");
     if (M == 0) return SETOK_OK;
-    GemmArgs g{A, W, bias, residual, C, lda, ldc, strideA, strideW, strideC, M, N, K, act};
+    GemmArgs g{A, W, bias, residual, C, lda, ldc, strideA, strideW, strideC, M, N, K, act, m_dev};
     hipStream_t s = (hipStream_t)stream;
     const double es_in = dtype == SETOK_BF16 ? 2.0 : 4.0, es_out = out_dtype == SETOK_BF16 ? 2.0 : 4.0;
     {
@@ -259,16 +269,16 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
         SETOK_CHECK_ARG(lda % 8 == 0, "setok_linear(bf16): lda must be a multiple of 8");
         // big problems (>= 48 tiles of 256x256; measured crossover against the 64x64 kernel: ~50 tiles): persistent direct-to-LDS kernel (gemm_persist.hip)
         if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= persist_min && !g_force_small_tiles)
-            return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr);
+            return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr, m_dev);
         // fp32-out batched problems without bias / activation / residual and with enough tiles (weight-gradient partial products)
-        if (out_dtype == SETOK_F32 && !bias && !residual && act == SETOK_ACT_NONE && N % 64 == 0 && K >= 192 && ldc % 4 == 0 &&
+        if (!m_dev && out_dtype == SETOK_F32 && !bias && !residual && act == SETOK_ACT_NONE && N % 64 == 0 && K >= 192 && ldc % 4 == 0 &&
             strideA % 8 == 0 && strideW % 8 == 0 && strideC % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) * batch >= 96 && !g_force_small_tiles)
             return setok_gemm_persist_f32_batched(s, (const bf16*)A, lda, (const bf16*)W, (float*)C, ldc, M, N, K, batch, strideA, strideW, strideC);
         // every other bf16 -> bf16 problem with N % 64 == 0: 64 x 64 tiles, eight-stage LDS-DMA pipeline (gemm_persist.hip).
         // SETOK_GEMM_SMALL64_MAXTILES=<n> (test hook) limits it to problems of at most n 128 x 128 tiles.
         {
             if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && ldc % 8 == 0 && cdiv(M, BM) * cdiv(N, BN) <= small_max && !g_force_small_tiles)
-                return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr);
+                return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr, m_dev);
         }
         dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
         if (out_dtype == SETOK_BF16) gemm_bf16_kernel<bf16, true><<<grid, 256, 0, s>>>(g);
@@ -287,6 +297,12 @@ extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* 
     return SETOK_OK;
 }
 
+extern "C" int setok_linear(void* stream, int dtype, int out_dtype, const void* A, int64_t lda, const void* W,
+                            const float* bias, const void* residual, void* C, int64_t ldc, int M, int N, int K,
+                            int act, int batch, int64_t strideA, int64_t strideW, int64_t strideC) {
+    return setok_linear_dev(stream, dtype, out_dtype, A, lda, W, bias, residual, C, ldc, M, N, K, act, batch, strideA, strideW, strideC, nullptr);
+}
+
 // LayerNorm folded into the consuming Linear (bf16 throughput mode; gemm_persist.hip explains the algebra).  Same kernel choice as
 // setok_linear makes for a bf16 -> bf16 problem, so a row's result does not depend on the batch it is computed in.
 extern "C" int setok_linear_ln(void* stream, const void* A, int64_t lda, const void* w_gamma, const float* col_frag, const float* row_stats,
@@ -301,6 +317,6 @@ extern "C" int setok_linear_ln(void* stream, const void* A, int64_t lda, const v
     SetokProfScope prof(s, SETOK_PROF_GEMM_BF16, act | 8, 2.0 * M * N * K, ((double)M * K + (double)N * K) * 2.0 + (double)M * N * 2.0 + (double)M * 32.0, true);
     static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();
     if (K >= 192 && cdiv(M, 256) * cdiv(N, 256) >= persist_min)
-        return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag);
-    return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag);
+        return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag, nullptr);
+    return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag, nullptr);
 }

@@ -44,6 +44,7 @@ struct PArgs {
     int nbatch;
     const float* ln_stats;       // LNK variant: per row of A 8 floats {row fragment (4 dwords), rstd, mean, 0, 0} (setok_row_stats): the LayerNorm folded into this GEMM
     const float* ln_colsum;      //   per column 4 dwords: the column fragment of c[n] = sum_k W'[n][k] and b'[n] = b[n] + sum_k W[n][k] beta[k] (setok_ln_fold)
+    const int32_t* m_dev;        // optional device-side row count (<= M): tiles beyond it are never visited (setok_linear_dev)
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     const int wm = wave / WNC, wn = wave % WNC;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
-    const int tiles_per_problem = g.tilesM * g.tilesN;
+    // rows of this launch: the host's M, or the device-side count of a ragged stage (uniform: one scalar load)
+    const int Mrt = g.m_dev ? min(g.M, __builtin_amdgcn_readfirstlane(*g.m_dev)) : g.M;
+    const int tilesMrt = g.m_dev ? (Mrt + TM - 1) / TM : g.tilesM;
+    const int tiles_per_problem = tilesMrt * g.tilesN;
     const int num_tiles = tiles_per_problem * (F32B ? g.nbatch : 1);
     const int G = gridDim.x;
     int bz = 0, nbz = 0;                           // batch member of the current / next tile (F32B)
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         if (F32B) { b = L / tiles_per_problem; L -= b * tiles_per_problem; }
         constexpr int GM = 8;
         const int per = GM * g.tilesN, group = L / per, first_m = group * GM;
-        const int gm = min(g.tilesM - first_m, GM), in = L - group * per;
+        const int gm = min(tilesMrt - first_m, GM), in = L - group * per;
         m0 = (first_m + in % gm) * TM;
         n0 = (in / gm) * TNB;
         return true;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = i * 512 + tid_e, row = p >> 3, kc = (p & 7) ^ swz(row);
-            a_off[i] = (unsigned)min(row, g.M - 1 - m0) * (unsigned)(g.lda * 2) + kc * 16;       // < 256 rows x lda x 2 bytes
+            a_off[i] = (unsigned)min(row, Mrt - 1 - m0) * (unsigned)(g.lda * 2) + kc * 16;       // < 256 rows x lda x 2 bytes
             b_off[i] = (unsigned)min(row, g.N - 1 - n0) * (unsigned)(g.K * 2) + kc * 16;
         }
     };
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
             ncw = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)(min(n0_ + wn * 64, g.N - 64) + g4 * 16 + l15));
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float* st = g.ln_stats + 8 * (int64_t)min(m0_ + wm * WR + (2 * g4 + i) * 16 + l15, g.M - 1);
+                const float* st = g.ln_stats + 8 * (int64_t)min(m0_ + wm * WR + (2 * g4 + i) * 16 + l15, Mrt - 1);
                 nrw[i] = *reinterpret_cast<const float2*>(st);
                 nrs[i] = st[4];
             }
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
         //        residual rows of pass 1 | stores of pass 0 | residual 2 | stores 1 | residual 3 | stores 2 | stores 3
         //      so the next tile waits vmcnt(NSTORE + 8) for its first K-tile and vmcnt(NSTORE) for its second, and no wait
         //      in here asks for a store to have completed.
-        const bool interior = (m0 + TM <= g.M) && (n0 + TNB <= g.N) && !(g.dbg & 1);
+        const bool interior = (m0 + TM <= Mrt) && (n0 + TNB <= g.N) && !(g.dbg & 1);
         constexpr bool use_res = RESK;
         // The lane-only parts of the store / residual addresses are recomputed per tile from an opaque copy of the lane id: hoisted out of
         // the tile loop they are ~30 registers that live across the main loop, get spilled, and come back one scratch load per store
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
-                if (decltype(int_tag)::value || (grow < g.M && col_ok))
+                if (decltype(int_tag)::value || (grow < Mrt && col_ok))
                     rv[0][it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
             }
         };
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int grow = m0 + wm * WR + h * 32 + it * 8 + lrow;
-                    if (INT || (grow < g.M && col_ok && !(g.dbg & 1)))
+                    if (INT || (grow < Mrt && col_ok && !(g.dbg & 1)))
                         *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];
                 }
             }
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int c = n0 + wn * 64 + j * 16 + 4 * g4;
-                    if (grow < g.M && c < g.N) {
+                    if (grow < Mrt && c < g.N) {
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[t][j][e];
@@ -498,11 +502,13 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
     const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TT;
+    const int Mrt = g.m_dev ? min(g.M, __builtin_amdgcn_readfirstlane(*g.m_dev)) : g.M;
+    if (m0 >= Mrt) return;                                  // a ragged stage's tiles beyond its device-side row count (before any barrier)
     float* sbias = reinterpret_cast<float*>(smem + TNS * TSTAGE);
     if (tid < 64) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
     if constexpr (LNK) {                                    // sbias[64..127] row rstds, then the 64 column fragments and the 64 row fragments (16 B each)
         if (tid < 64) {
-            const float* st = g.ln_stats + 8 * (int64_t)min(m0 + tid, g.M - 1);
+            const float* st = g.ln_stats + 8 * (int64_t)min(m0 + tid, Mrt - 1);
             sbias[64 + tid] = st[4];
             reinterpret_cast<f32x4*>(sbias + 128)[tid] = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)min(n0 + tid, g.N - 1));
             const f32x4 rf = {st[0], st[0], st[1], st[1]};        // compact (-mean hi, lo), (1 / rstd hi, lo) -> the 8 k-slots
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
-        a_src[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+        a_src[i] = g.A + (int64_t)min(m0 + row, Mrt - 1) * g.lda + kc * 8;
         b_src[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
         const int row = it * 32 + (tid >> 3);
         const int grow = m0 + row;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
-        if (grow < g.M && col < g.N && !(g.dbg & 1)) {
+        if (grow < Mrt && col < g.N && !(g.dbg & 1)) {
             if (g.res && !(g.dbg & 2)) {
                 const bf16x8 rv = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
 #pragma unroll
@@ -698,7 +704,7 @@ const float* zero_bias() {                          // the current device's copy
 
 // Called by setok_linear (gemm.hip) for bf16 -> bf16 problems with >= 48 tiles of 256x256.
 int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                            bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum) {
+                            bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev) {
     const int ncu = cu_count();
     const int tilesM = cdiv(M, TM), tilesN = cdiv(N, 256);
     // Peel off p <= 2 trailing M-tiles when that leaves the main launch an exact number of rounds: the
@@ -717,14 +723,14 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 #endif
         return v;
     }();
-    if (dbg & 4) p = 0;
+    if (dbg & 4 || m_dev) p = 0;                                    // a device-side row count: no host-side split of M
     if (dbg & 8) p = tilesM;                                        // experiment: everything through the deep-pipeline 64x64 kernel
     const int tm_main = tilesM - p;
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
     PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1,
-            ln_stats, ln_colsum};
+            ln_stats, ln_colsum, m_dev};
     if (!bias) {
         const float* zb = zero_bias();
         if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
@@ -747,15 +753,15 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int m_off = tm_main * TM;
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
             lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1,
-            ln_stats ? ln_stats + 8 * (int64_t)m_off : nullptr, ln_colsum};
+            ln_stats ? ln_stats + 8 * (int64_t)m_off : nullptr, ln_colsum, nullptr};
     return launch_tail(s, t, act, has_main ? nullptr : setok_prof_start_event(), setok_prof_stop_event());
 }
 
 // Called by setok_linear for SMALL bf16 -> bf16 problems (a handful of images: too few 128 x 128 tiles to fill 256 CUs): the deep-pipelined
 // 64 x 64 kernel over the whole problem.
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
-                          bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum) {
-    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, TT), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum};
+                          bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev) {
+    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, TT), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum, m_dev};
     const hipEvent_t e0 = setok_prof_start_event();
     return launch_tail(s, t, act, e0, setok_prof_stop_event());
 }
@@ -770,7 +776,7 @@ int setok_gemm_persist_f32_batched(hipStream_t s, const bf16* A, int64_t lda, co
     const float* zb = zero_bias();
     if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
     const int tilesM = cdiv(M, TM), tilesN = cdiv(N, 256);
-    PArgs g{A, W, nullptr, nullptr, nullptr, lda, ldc, M, N, K, tilesM, tilesN, 0, nullptr, zb, C, sA, sW, sC, batch, nullptr, nullptr};
+    PArgs g{A, W, nullptr, nullptr, nullptr, lda, ldc, M, N, K, tilesM, tilesN, 0, nullptr, zb, C, sA, sW, sC, batch, nullptr, nullptr, nullptr};
     const int tiles = tilesM * tilesN * batch, ncu = cu_count();
     gemm_persist_kernel<0, true><<<tiles < ncu ? tiles : ncu, 512, MAIN_LDS, s>>>(g);
     SETOK_CHECK_LAUNCH("setok_linear(persistent, fp32 batched)");

@@ -8,10 +8,11 @@
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* y,
-                                                        int rows, int C, float eps) {
+                                                        int rows, int C, float eps, const int32_t* __restrict__ rows_dev) {
     constexpr int V = Elem<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rows_dev) rows = min(rows, *rows_dev);                     // a ragged stage's device-side row count (setok_encode)
     if (row >= rows) return;
     const T* xr = x + (int64_t)row * C;
     T* yr = y + (int64_t)row * C;
@@ -43,10 +44,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
 // Same arithmetic and summation order as the generic kernel above (results are bit-identical).
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, T* y, int rows, float eps) {
+                                                             const float* __restrict__ beta, T* y, int rows, float eps,
+                                                             const int32_t* __restrict__ rows_dev) {
     constexpr int V = Elem<T>::VEC, C = NCH * 64 * V;
     const int lane = threadIdx.x & 63;
     const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    if (rows_dev) rows = min(rows, *rows_dev);
+    if (wave0 >= rows) return;
     float g[NCH][V], b[NCH][V];
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
@@ -80,31 +84,37 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const f
 }
 
 template <typename T, int NCH>
-static void launch_ln_rows(hipStream_t s, const void* x, const float* gamma, const float* beta, void* y, int rows, float eps) {
+static void launch_ln_rows(hipStream_t s, const void* x, const float* gamma, const float* beta, void* y, int rows, float eps, const int32_t* rows_dev) {
     const int grid = min(cdiv(rows, 4), 256 * 8);
-    layernorm_rows_kernel<T, NCH><<<grid, 256, 0, s>>>((const T*)x, gamma, beta, (T*)y, rows, eps);
+    layernorm_rows_kernel<T, NCH><<<grid, 256, 0, s>>>((const T*)x, gamma, beta, (T*)y, rows, eps, rows_dev);
 }
 
-extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const float* gamma, const float* beta,
-                               void* y, int rows, int C, float eps) {
+// rows_dev: optional device-side row count (<= rows); rows beyond it are neither read nor written.
+int setok_layernorm_dev(void* stream, int dtype, const void* x, const float* gamma, const float* beta,
+                        void* y, int rows, int C, float eps, const int32_t* rows_dev) {
     SETOK_CHECK_ARG(x && y && gamma && beta, "setok_layernorm: null operand");
     SETOK_CHECK_ARG(rows >= 0 && C > 0 && C % 8 == 0, "setok_layernorm: C=%d must be a positive multiple of 8", C);
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(rows, 4));
     if (dtype == SETOK_BF16 && (C == 512 || C == 1024 || C == 1536 || C == 2048) && rows >= 1024) {
-        if (C == 512) launch_ln_rows<bf16, 1>(s, x, gamma, beta, y, rows, eps);
-        else if (C == 1024) launch_ln_rows<bf16, 2>(s, x, gamma, beta, y, rows, eps);
-        else if (C == 1536) launch_ln_rows<bf16, 3>(s, x, gamma, beta, y, rows, eps);
-        else launch_ln_rows<bf16, 4>(s, x, gamma, beta, y, rows, eps);
+        if (C == 512) launch_ln_rows<bf16, 1>(s, x, gamma, beta, y, rows, eps, rows_dev);
+        else if (C == 1024) launch_ln_rows<bf16, 2>(s, x, gamma, beta, y, rows, eps, rows_dev);
+        else if (C == 1536) launch_ln_rows<bf16, 3>(s, x, gamma, beta, y, rows, eps, rows_dev);
+        else launch_ln_rows<bf16, 4>(s, x, gamma, beta, y, rows, eps, rows_dev);
         SETOK_CHECK_LAUNCH("setok_layernorm");
         return SETOK_OK;
     }
-    if (dtype == SETOK_BF16) layernorm_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, gamma, beta, (bf16*)y, rows, C, eps);
-    else if (dtype == SETOK_F32) layernorm_kernel<float><<<grid, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, eps);
+    if (dtype == SETOK_BF16) layernorm_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, gamma, beta, (bf16*)y, rows, C, eps, rows_dev);
+    else if (dtype == SETOK_F32) layernorm_kernel<float><<<grid, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, rows, C, eps, rows_dev);
     else return setok_fail(SETOK_EINVAL, "setok_layernorm: bad dtype %d", dtype);
     SETOK_CHECK_LAUNCH("setok_layernorm");
     return SETOK_OK;
+}
+
+extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const float* gamma, const float* beta,
+                               void* y, int rows, int C, float eps) {
+    return setok_layernorm_dev(stream, dtype, x, gamma, beta, y, rows, C, eps, nullptr);
 }
 
 // --------------------------------------------------------------------------------------------
