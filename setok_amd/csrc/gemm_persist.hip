@@ -488,39 +488,49 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 // wait counted.  Same arithmetic per output element as the main kernel (bias as accumulator init, ascending k, one bf16 rounding,
 // round-then-add residual): a row's result does not depend on which kernel produced it.
 // --------------------------------------------------------------------------------------------
-constexpr int TT = 64;                           // tail tile edge
-constexpr int TSTAGE = 2 * TT * TK * 2;          // A 8 KiB + W 8 KiB
-constexpr int TNS = 8;                           // stages
-constexpr int TAIL_LDS = TNS * TSTAGE + 2560;    // + bias row (+ LNK: row rstds, 64 column fragments, 64 row fragments)
+constexpr int TT = 64;                           // tail tile edge (M; and N of the default shape)
+constexpr int TNS = 8;                           // stages of the default shape
+__host__ __device__ constexpr int tail_stage(int ttn) { return (TT + ttn) * TK * 2; }          // A 8 KiB + W 8 / 4 KiB
+__host__ __device__ constexpr int tail_lds(int ttn, int ns) { return ns * tail_stage(ttn) + 2560; }   // + bias row (+ LNK: row rstds, column / row fragments)
 
-template <int ACT, bool LNK = false>
+// TTN: columns per tile (64, or 32 for problems with too few 64 x 64 tiles to occupy the chip: twice the workgroups, each streaming 3/4 of
+// the bytes); NS: pipeline stages (8, or 4 = 66 KiB so that TWO workgroups fit a CU when a launch has more tiles than CUs).  The arithmetic
+// per output element does not depend on either.
+template <int ACT, bool LNK = false, int TTN = 64, int NS = TNS>
 __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
+    constexpr int NJ = TTN / 32;                            // 16-column MFMA tiles per wave along N (wave = 32 rows x TTN / 2 columns)
+    constexpr int LPT = 2 + NJ;                             // LDS-DMA loads per lane per K-tile: 2 of A, TTN / 32 of W
+    constexpr int STG = tail_stage(TTN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
-    const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TT;
+    const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TTN;
     const int Mrt = g.m_dev ? min(g.M, __builtin_amdgcn_readfirstlane(*g.m_dev)) : g.M;
     if (m0 >= Mrt) return;                                  // a ragged stage's tiles beyond its device-side row count (before any barrier)
-    float* sbias = reinterpret_cast<float*>(smem + TNS * TSTAGE);
-    if (tid < 64) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
-    if constexpr (LNK) {                                    // sbias[64..127] row rstds, then the 64 column fragments and the 64 row fragments (16 B each)
+    float* sbias = reinterpret_cast<float*>(smem + NS * STG);
+    if (tid < TTN) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
+    if constexpr (LNK) {                                    // sbias[64..127] row rstds, then the column fragments and the 64 row fragments (16 B each)
         if (tid < 64) {
             const float* st = g.ln_stats + 8 * (int64_t)min(m0 + tid, Mrt - 1);
             sbias[64 + tid] = st[4];
-            reinterpret_cast<f32x4*>(sbias + 128)[tid] = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)min(n0 + tid, g.N - 1));
+            if (tid < TTN) reinterpret_cast<f32x4*>(sbias + 128)[tid] = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)min(n0 + tid, g.N - 1));
             const f32x4 rf = {st[0], st[0], st[1], st[1]};        // compact (-mean hi, lo), (1 / rstd hi, lo) -> the 8 k-slots
             reinterpret_cast<f32x4*>(sbias + 384)[tid] = rf;
         }
     }
 
-    const bf16* a_src[2]; const bf16* b_src[2];
+    const bf16* a_src[2]; const bf16* b_src[NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
         a_src[i] = g.A + (int64_t)min(m0 + row, Mrt - 1) * g.lda + kc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
         b_src[i] = g.W + (int64_t)min(n0 + row, g.N - 1) * g.K + kc * 8;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
@@ -529,78 +539,83 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(ptr), "s"(lds_dst) : "memory");
     };
-    auto issue = [&](int kt) {                              // 4 loads per lane per K-tile
-        const unsigned sb = lds0 + (kt % TNS) * TSTAGE;
+    auto issue = [&](int kt) {                              // LPT loads per lane per K-tile
+        const unsigned sb = lds0 + (kt % NS) * STG;
         const int k0 = kt * TK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(a_src[i] + k0, sb + i * 4096);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(b_src[i] + k0, sb + TT * TK * 2 + i * 4096);
+        for (int i = 0; i < NJ; ++i) dma16(b_src[i] + k0, sb + TT * TK * 2 + i * 4096);
     };
-    for (int kt = 0; kt < TNS - 1 && kt < nk; ++kt) issue(kt);
+    for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) issue(kt);
 
-    f32x4 acc[2][2];                                        // this wave's 32 x 32: 2 x 2 MFMA tiles of 16 x 16
+    f32x4 acc[2][NJ];                                       // this wave's 32 x (TTN / 2): 2 x NJ MFMA tiles of 16 x 16
     for (int kt = 0; kt < nk; ++kt) {
-        // K-tile kt has landed for this wave: at most the 4 * min(6, nk - 1 - kt) younger loads may still fly
-        switch (min(TNS - 2, nk - 1 - kt)) {
-            case 6: wait_vm<24>(); break;
-            case 5: wait_vm<20>(); break;
-            case 4: wait_vm<16>(); break;
-            case 3: wait_vm<12>(); break;
-            case 2: wait_vm<8>(); break;
-            case 1: wait_vm<4>(); break;
+        // K-tile kt has landed for this wave: at most the LPT * min(NS - 2, nk - 1 - kt) younger loads may still fly
+        switch (min(NS - 2, nk - 1 - kt)) {
+            case 6: wait_vm<LPT * 6>(); break;
+            case 5: wait_vm<LPT * 5>(); break;
+            case 4: wait_vm<LPT * 4>(); break;
+            case 3: wait_vm<LPT * 3>(); break;
+            case 2: wait_vm<LPT * 2>(); break;
+            case 1: wait_vm<LPT>(); break;
             default: wait_vm<0>(); break;
         }
         s_barrier_lgkm();                                   // everyone's pieces; everyone is done with the stage of K-tile kt - 1 ...
-        if (kt + TNS - 1 < nk) issue(kt + TNS - 1);         // ... which is the stage K-tile kt + 7 goes to
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);           // ... which is the stage K-tile kt + NS - 1 goes to
         if (kt == 0) {
             if constexpr (LNK) {                                // the same fragments, the same instruction as the persistent kernel: identical bits
                 f32x4 z;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) z[e] = 0.f;
-                bf16x8 cfr[2];
+                bf16x8 cfr[NJ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) cfr[j] = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 128)[wn * 32 + j * 16 + l15], g4);
+                for (int j = 0; j < NJ; ++j) cfr[j] = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 128)[wn * (TTN / 2) + j * 16 + l15], g4);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const bf16x8 rfr = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 384)[wm * 32 + t * 16 + l15], g4);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float b = sbias[wn * 32 + j * 16 + 4 * g4 + e];
+                        const float b = sbias[wn * (TTN / 2) + j * 16 + 4 * g4 + e];
                         acc[0][j][e] = b; acc[1][j][e] = b;
                     }
             }
         }
-        const char* Ab = smem + (kt % TNS) * TSTAGE;
+        const char* Ab = smem + (kt % NS) * STG;
         const char* Bb = Ab + TT * TK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[2], af[2];
+            bf16x8 wf[NJ], af[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int rb = wn * 32 + t * 16 + l15, ra = wm * 32 + t * 16 + l15;
-                wf[t] = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 4 + g4) ^ swz(rb)) << 4));
+                const int ra = wm * 32 + t * 16 + l15;
                 af[t] = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 4 + g4) ^ swz(ra)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int rb = wn * (TTN / 2) + j * 16 + l15;
+                wf[j] = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 4 + g4) ^ swz(rb)) << 4));
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[t], acc[t][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[t], acc[t][j], 0, 0, 0);
         }
     }
-    // epilogue: the 64 x 64 tile is transposed through stage 0 (every load has landed; the barrier orders the last reads)
+    // epilogue: the 64 x TTN tile is transposed through stage 0 (every load has landed; the barrier orders the last reads); rows of 2 * TTN bytes
     s_barrier_lgkm();
     char* stg = smem;
+    constexpr int RB = TTN * 2, NSL = TTN / 8;              // bytes / 16-byte slots per staged row
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             bf16x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -610,16 +625,18 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
                 else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                 v[e] = (bf16)x;
             }
-            const int row = wm * 32 + t * 16 + l15;                 // columns wn * 32 + j * 16 + 4 * g4 .. + 3
-            *reinterpret_cast<bf16x4*>(stg + row * 128 + (((wn * 4 + j * 2 + (g4 >> 1)) ^ (row & 7)) << 4) + 8 * (g4 & 1)) = v;
+            const int row = wm * 32 + t * 16 + l15;                 // columns wn * TTN / 2 + j * 16 + 4 * g4 .. + 3
+            const int sl = wn * (NSL / 2) + j * 2 + (g4 >> 1);
+            *reinterpret_cast<bf16x4*>(stg + row * RB + ((sl ^ (row & (NSL - 1))) << 4) + 8 * (g4 & 1)) = v;
         }
     s_barrier_lgkm();
-    const int slot = tid & 7, col = n0 + slot * 8;
+    const int slot = tid & (NSL - 1), col = n0 + slot * 8;
+    constexpr int RPP = 256 / NSL;                          // rows per pass of the 256 threads
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int row = it * 32 + (tid >> 3);
+    for (int it = 0; it < TT / RPP; ++it) {
+        const int row = it * RPP + tid / NSL;
         const int grow = m0 + row;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * RB + ((slot ^ (row & (NSL - 1))) << 4));
         if (grow < Mrt && col < g.N && !(g.dbg & 1)) {
             if (g.res && !(g.dbg & 2)) {
                 const bf16x8 rv = *reinterpret_cast<const bf16x8*>(g.res + (int64_t)grow * g.ldc + col);
@@ -631,26 +648,48 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     }
 }
 
-int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1) {
+// Shape of the small-tile launch for a problem (host side).  64 x 64 tiles with eight stages is the default (the M-tail of the persistent kernel
+// always uses it).  Whole small problems: fewer than half a chip of 64 x 64 tiles -> 64 x 32 tiles (twice the workgroups); more tiles than CUs but
+// fewer than two rounds -> four stages (66 KiB), so that two workgroups share a CU and the launch is ONE round.  SETOK_GEMM_SMALL_SHAPE=0 keeps the
+// default everywhere (A/B runs).
+struct TailShape { int ttn, ns; };
+static TailShape tail_shape_for(int M, int N, int ncu, bool whole_problem) {
+    static const bool off = [] { const char* e = getenv("SETOK_GEMM_SMALL_SHAPE"); return e && e[0] == '0'; }();
+    if (!whole_problem || off) return {64, TNS};
+    const int t64 = cdiv(M, TT) * cdiv(N, 64);
+    if (t64 * 2 <= ncu && N % 32 == 0) return {32, TNS};
+    if (t64 > ncu && t64 <= 2 * ncu) return {64, 4};
+    return {64, TNS};
+}
+
+template <int TTN, int NS>
+static int launch_tail_shape(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1) {
     static SetokDeviceOnce once;
     if (!once.run([] {
             bool ok = true;
-            const void* fns[] = {(const void*)gemm_tail_kernel<0>, (const void*)gemm_tail_kernel<1>, (const void*)gemm_tail_kernel<2>,
-                                 (const void*)gemm_tail_kernel<0, true>, (const void*)gemm_tail_kernel<1, true>, (const void*)gemm_tail_kernel<2, true>};
-            for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) == hipSuccess;
+            const void* fns[] = {(const void*)gemm_tail_kernel<0, false, TTN, NS>, (const void*)gemm_tail_kernel<1, false, TTN, NS>, (const void*)gemm_tail_kernel<2, false, TTN, NS>,
+                                 (const void*)gemm_tail_kernel<0, true, TTN, NS>, (const void*)gemm_tail_kernel<1, true, TTN, NS>, (const void*)gemm_tail_kernel<2, true, TTN, NS>};
+            for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(TTN, NS)) == hipSuccess;
             return ok; }))
         return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
+    constexpr int LDS = tail_lds(TTN, NS);
     const int grid = g.tilesM * g.tilesN;
     const dim3 gr(grid), bl(256);
     if (g.ln_stats) {
-        if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, true>, gr, bl, TAIL_LDS, s, e0, e1, g);
-        else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, true>, gr, bl, TAIL_LDS, s, e0, e1, g);
-        else setok_launch(gemm_tail_kernel<2, true>, gr, bl, TAIL_LDS, s, e0, e1, g);
-    } else if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, false>, gr, bl, TAIL_LDS, s, e0, e1, g);
-    else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, false>, gr, bl, TAIL_LDS, s, e0, e1, g);
-    else setok_launch(gemm_tail_kernel<2, false>, gr, bl, TAIL_LDS, s, e0, e1, g);
+        if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, true, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, true, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        else setok_launch(gemm_tail_kernel<2, true, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+    } else if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, false, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+    else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, false, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+    else setok_launch(gemm_tail_kernel<2, false, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
     SETOK_CHECK_LAUNCH("setok_linear(tail)");
     return SETOK_OK;
+}
+
+int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1, TailShape sh = {64, TNS}) {
+    if (sh.ttn == 32) return launch_tail_shape<32, TNS>(s, g, act, e0, e1);
+    if (sh.ns == 4) return launch_tail_shape<64, 4>(s, g, act, e0, e1);
+    return launch_tail_shape<64, TNS>(s, g, act, e0, e1);
 }
 
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0, hipEvent_t e1) {
@@ -761,9 +800,10 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 // 64 x 64 kernel over the whole problem.
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                           bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev) {
-    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, TT), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum, m_dev};
+    const TailShape sh = tail_shape_for(M, N, cu_count(), true);
+    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, sh.ttn), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum, m_dev};
     const hipEvent_t e0 = setok_prof_start_event();
-    return launch_tail(s, t, act, e0, setok_prof_stop_event());
+    return launch_tail(s, t, act, e0, setok_prof_stop_event(), sh);
 }
 
 // Called by setok_linear for bf16 -> fp32 batched problems (no bias / activation / residual): the split-K partial products of a weight

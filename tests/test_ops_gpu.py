@@ -91,11 +91,14 @@ def test_linear_bf16_large_no_bias_and_alias():
     assert _rel_err(buf, ref.bfloat16().double() + r.double()) < 6e-3
 
 
+@pytest.mark.parametrize("N,K", [(1024, 1024), (4096, 1024), (1024, 4096)])
 @pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (2, True), (0, True)])
-def test_linear_bf16_rows_do_not_depend_on_the_kernel(act, use_res):
-    """The same rows through the persistent 256 x 256 kernel (M = 25 k: 392 tiles), through its 64 x 64 tail / small-problem kernel
-    (M = 257, 63, 1) and inside a mid-size problem give the same bits: a sample alone equals the sample inside a batch."""
-    M, N, K = 25088, 1024, 1024
+def test_linear_bf16_rows_do_not_depend_on_the_kernel(act, use_res, N, K):
+    """The same rows through the persistent 256 x 256 kernel (M = 25 k: 392 tiles), through its small-problem kernel in all three shapes
+    (64 x 32 tiles where 64 x 64 ones would leave half the chip idle: M = 1, 63, 257 at N = 1024; four stages / two workgroups per CU where
+    there are more tiles than CUs: M = 1028 at N = 1024, M = 257 at N = 4096; 64 x 64 with eight stages otherwise) and inside a mid-size
+    problem give the same bits: a sample alone equals the sample inside a batch."""
+    M = 25088
     a, w = _rand(M, K, seed=11).bfloat16().to(DEV), (_rand(N, K, seed=12, scale=K ** -0.5)).bfloat16().to(DEV)
     b = _rand(N, seed=13).to(DEV)
     r = _rand(M, N, seed=14).bfloat16().to(DEV) if use_res else None
