@@ -593,6 +593,441 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
 }
 }  // namespace
 
+// --------------------------------------------------------------------------------------------
+// 256 < N <= 576 tokens (BASELINE config 4: ViT-L/14-336, 24 x 24 patches), bf16: ONE launch, no N x N workspace.
+//
+// 331 k distances do not fit the registers of one CU (131 k per CU), so an image is cut into STRIPS of 128 rows: a workgroup holds its strip
+// (128 rows x all 576 columns) in its MFMA accumulators — wave w owns rows [16 w, 16 w + 16) of the strip = 36 tiles of 16 x 16 = 144 registers per
+// lane, a row again shared by the four lanes {l, l + 16, l + 32, l + 48} — and runs every per-row step on it exactly as dpc_fused_kernel does
+// (distances in place, row max, radix-select density, delta / score, nearest-centre argmin along the token's own row).  What a strip needs from the
+// OTHER strips of its image is three vectors of N floats, exchanged through global memory inside the launch:
+//   |x_j|^2 of all columns      none: the 36 diagonal 16 x 16 blocks are multiplied redundantly by every workgroup (+12 % MFMAs; the same
+//                                instruction on the same operands as the block in its owner's accumulators: bit-identical, D stays symmetric)
+//   rho_j, rowmax_j              exchange 1 (after the density)          tokenizer.py:96-99 compares against every other token
+//   score_j                      exchange 2 (after delta)                tokenizer.py:103-107 ranks all tokens; every workgroup then selects the
+//                                                                        centres itself (identical results), strip 0 writes index_down / counts
+//   (token_mask: the global maximum of the raw distances, exchange 0)    tokenizer.py:84-86
+// An exchange = plain stores -> workgroup barrier -> ONE agent-scope release + a relaxed counter increment; the readers poll the counter (relaxed),
+// take ONE agent-scope acquire, and read with plain loads (cdna guide, Guideline 16).  Every strip writes whole 128-byte lines of its own; the
+// counters live in a line of their own.
+// Deadlock freedom without any assumption on dispatch order: the grid is PERSISTENT (at most one workgroup per CU: all co-resident) and pulls
+// (image, strip) items from queues in image-major order, so the strips of an image are taken by workgroups that are running at the same time;
+// whatever a workgroup waits for has either been pulled by a running workgroup or is next in a queue that workgroups finishing complete images keep
+// draining (at most 8 x 4 workgroups can ever hold items of incompletely pulled images).  One queue per XCD (images b = x mod 8, blocks x mod 8 —
+// observed placement, a speed matter only): the strips of an image re-read its x through ONE L2.
+// --------------------------------------------------------------------------------------------
+namespace {
+constexpr int SN = 576, SNT = SN / 16, SROWS = 128;
+constexpr int S_STAGE = SN * 128;                       // one K-tile: 576 rows x 64 channels x 2 B = 72 KiB
+constexpr int S_LDS = 2 * S_STAGE + 256;               // + the item word
+constexpr int S_HDR = 32;                               // workspace header (ints): [0..7] queue heads
+constexpr int S_IMG = 3 * SN + 8 * 32 + 32;             // per image (floats): rho, rmax, score; 8 lines of one strip's raw maximum each; one line of counters
+
+struct SArgs {
+    const bf16* x; const float* noise; const float* tmask;
+    int64_t* idx; float* score; int64_t* index_down; int32_t* counts;
+    float* ws;
+    int B, N, C, k, mcn, strips;
+    float thr, sqrtC, inv_sqrtC;
+    int scale_by_mul;
+};
+
+__device__ inline void strip_publish(int* counter) {          // every thread's plain stores of the exchange are issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ inline void strip_wait(int* counter, int target) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(512) void dpc_strip_kernel(SArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_item = reinterpret_cast<int*>(smem + 2 * S_STAGE);
+    // after the Gram product the two stages are free: the per-token vectors live in stage 0
+    float* s_norm = reinterpret_cast<float*>(smem);                         // [640]
+    float* s_rho = s_norm + 640;                                            // [640]  density; -1 for tokens >= N
+    float* s_rmax = s_rho + 640;                                            // [640]  row max; +inf for tokens >= N
+    float* s_score = s_rmax + 640;                                          // [640]
+    int* s_rank = reinterpret_cast<int*>(s_score + 640);                    // [640]  position of token i in the centre list
+    float* s_red = reinterpret_cast<float*>(s_rank + 640);                  // [16]
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_red + 16);   // [0..9] centre flags, [16..25] token_mask bits
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int N = g.N, S = g.strips;
+    const float INF = __builtin_inff();
+    int* heads = reinterpret_cast<int*>(g.ws);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
+    const int home = blockIdx.x & 7;
+
+    for (;;) {
+        // ---- next (image, strip): the home queue first, then the others ------------------------------------------------------------------------
+        if (tid == 0) {
+            int it = -1;
+            for (int o = 0; o < 8 && it < 0; ++o) {
+                const int x = (home + o) & 7;
+                const int per = (g.B - x + 7) / 8;                           // images x, x + 8, ... < B
+                if (per <= 0) continue;
+                if (__hip_atomic_load(heads + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per * S) continue;
+                const int q = __hip_atomic_fetch_add(heads + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q < per * S) it = ((x + 8 * (q / S)) << 4) | (q % S);
+            }
+            *s_item = it;
+        }
+        __syncthreads();
+        const int item = *s_item;
+        if (item < 0) return;
+        const int b = item >> 4, strip = item & 15;
+        const bf16* Xb = g.x + (int64_t)b * N * g.C;
+        float* wimg = g.ws + S_HDR + (int64_t)b * S_IMG;
+        float* w_rho = wimg, *w_rmax = wimg + SN, *w_score = wimg + 2 * SN, *w_raw = wimg + 3 * SN;
+        int* w_cnt = reinterpret_cast<int*>(wimg + 3 * SN + 8 * 32);
+
+        // ---- Gram strip: rows [128 strip, + 128) x all columns; the diagonal blocks of ALL column tiles on the side -------------------------
+        // LDS-DMA source: piece p = 512 i + tid -> row p >> 3 = 64 i + (tid >> 3), 16-byte slot (p & 7) ^ swizzle(row); the swizzle (row >> 1) & 7
+        // does not depend on i (64 i >> 1 is a multiple of 8), so ONE lane offset serves all nine pieces and the row advance of 64 rows goes into
+        // the wave-uniform base; only when N < 576 the last pieces' rows are clamped to N - 1 (per-lane offsets, computed on the fly).
+        const int prow = tid >> 3;
+        const unsigned poff = (unsigned)prow * (unsigned)(g.C * 2) + (unsigned)(((tid & 7) ^ f_swz(prow)) << 4);
+        auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
+            unsigned keep;
+            const unsigned long long b64 = (unsigned long long)base;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+            const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
+        };
+        const bool full = N == SN;                          // uniform
+        auto issue = [&](int kt) {
+            const unsigned sb = lds0 + (kt & 1) * S_STAGE;
+            const char* base = reinterpret_cast<const char*>(Xb) + (size_t)kt * 128;
+            if (full) {
+#pragma unroll 1
+                for (int i = 0; i < 9; ++i) dma16(base + (size_t)i * 64 * (size_t)(g.C * 2), poff, sb + i * 8192);
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < 9; ++i) {
+                    const unsigned off = (unsigned)min(prow + 64 * i, N - 1) * (unsigned)(g.C * 2) + (unsigned)(((tid & 7) ^ f_swz(prow)) << 4);
+                    dma16(base, off, sb + i * 8192);
+                }
+            }
+        };
+        f32x4 acc[SNT];
+        f32x4 accd[5];                                    // diagonal blocks of column tiles wave, wave + 8, ... (< 36)
+#pragma unroll
+        for (int t = 0; t < SNT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accd[i][e] = 0.f;
+        const int nk = g.C / 64;
+        const int lrow = min(strip * SROWS + wave * 16 + l15, SN - 1);            // this lane's row of the LDS tile (rows >= N hold row N - 1: finite, unused)
+        issue(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's pieces of K-tile kt
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // everyone's; everyone is done reading the other stage
+            if (kt + 1 < nk) issue(kt + 1);
+            const char* T = smem + (kt & 1) * S_STAGE;
+            const char* rowp = T + lrow * 128;
+            const char* colp = T + l15 * 128;
+            const int sw = f_swz(l15), swr = f_swz(lrow);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 rf = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + g4) ^ swr) << 4));
+                const int so = ((ks * 4 + g4) ^ sw) << 4;
+#pragma unroll
+                for (int bt = 0; bt < 6; ++bt) {                                  // the 36 column fragments in six batches of six
+                    bf16x8 cf[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) cf[u] = *reinterpret_cast<const bf16x8*>(colp + (bt * 6 + u) * 2048 + so);
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) acc[bt * 6 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[u], rf, acc[bt * 6 + u], 0, 0, 0);
+                }
+                // the diagonal blocks of column tiles wave, wave + 8, ... : their own fragment reads (a wave-uniform tile offset), no branches
+                {
+                    bf16x8 df[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) df[i] = *reinterpret_cast<const bf16x8*>(colp + min(wave + 8 * i, SNT - 1) * 2048 + so);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) accd[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], df[i], accd[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done with the stages: stage 0 now holds the per-token vectors
+
+        // ---- norms = the Gram diagonal, for every column -----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = wave + 8 * i;
+            if (t < SNT) {
+                const int c = l15 & 3;
+                const float dv = c == 0 ? accd[i][0] : (c == 1 ? accd[i][1] : (c == 2 ? accd[i][2] : accd[i][3]));
+                if (g4 == (l15 >> 2)) s_norm[t * 16 + l15] = dv;
+            }
+        }
+        __syncthreads();
+
+        // ---- distances in place; raw row max ----------------------------------------------------------------------------------------------------
+        const int row = strip * SROWS + wave * 16 + l15;   // token index of this lane's row
+        const bool rvalid = row < N;
+        const int tself = strip * 8 + wave;                // the column tile that holds the diagonal of this wave's rows
+        const float ni = s_norm[min(row, SN - 1)];
+        float mx = 0.f;
+        // (the item loop makes N and the lane's column indices loop invariants: hoisted, the 144 column-validity masks and indices are 288 + 144
+        // registers that live across the whole kernel and spill — an opaque copy per item keeps them where they are used)
+        int Nrt = N, c4 = 4 * g4;
+        asm volatile("" : "+s"(Nrt));
+        asm volatile("" : "+v"(c4));
+#pragma unroll
+        for (int t = 0; t < SNT; ++t) {
+            const f32x4 nj = *reinterpret_cast<const f32x4*>(s_norm + t * 16 + 4 * g4);
+            if (t % 6 == 5) __builtin_amdgcn_sched_barrier(0);               // (keeps the 36 vector reads from being issued in one cluster)
+            if ((t + 1) * 16 <= Nrt) {                                        // a whole tile of real columns (all of them at N = 576): no masks
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = __builtin_amdgcn_sqrtf(fmaxf((ni + nj[e]) - 2.0f * acc[t][e], 0.f));
+                    if (g.scale_by_mul) d *= g.inv_sqrtC; else d = d / g.sqrtC;
+                    acc[t][e] = d;
+                    mx = fmaxf(mx, d);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = t * 16 + c4 + e < Nrt;
+                    float d = __builtin_amdgcn_sqrtf(fmaxf((ni + nj[e]) - 2.0f * acc[t][e], 0.f));
+                    if (g.scale_by_mul) d *= g.inv_sqrtC; else d = d / g.sqrtC;
+                    acc[t][e] = ok ? d : INF;                                 // columns beyond N: never nearest, never a centre
+                    mx = fmaxf(mx, ok ? d : 0.f);
+                }
+            }
+        }
+        mx = row4_maxf(mx);
+
+        // ---- token_mask (:84-86): masked columns read (global max + 1) everywhere -------------------------------------------------------------------
+        constexpr bool masked = MASKED;
+        float fill = 0.f;
+        unsigned tmw[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // bit (t & 7) * 4 + e of word t >> 3
+        bool tm_row = true;
+        if constexpr (MASKED) {
+            float sm = rvalid ? mx : 0.f;                                        // the strip's raw maximum
+            sm = wave_max(sm);
+            if (lane == 0) s_red[wave] = sm;
+            for (int i = tid; i < 640; i += 512) {
+                const bool on = i < N && g.tmask[(int64_t)b * N + i] > 0.f;
+                const unsigned long long bal = __ballot(on);
+                if (lane == 0) s_mask[16 + (i >> 6)] = bal;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float m8 = 0.f;
+                for (int w = 0; w < 8; ++w) m8 = fmaxf(m8, s_red[w]);
+                w_raw[strip * 32] = m8;
+            }
+            strip_publish(w_cnt + 0);
+            strip_wait(w_cnt + 0, S);
+            float gm = 0.f;
+            for (int q = 0; q < S; ++q) gm = fmaxf(gm, w_raw[q * 32]);
+            fill = gm + 1.0f;
+#pragma unroll
+            for (int t = 0; t < SNT; ++t) {
+                const unsigned nib = (unsigned)(s_mask[16 + (t >> 2)] >> ((t & 3) * 16 + 4 * g4)) & 0xfu;
+                tmw[t >> 3] = (t & 7) == 0 ? nib : (tmw[t >> 3] | (nib << ((t & 7) * 4)));
+            }
+            tm_row = rvalid && ((s_mask[16 + (row >> 6)] >> (row & 63)) & 1ull);
+            mx = 0.f;
+#pragma unroll
+            for (int t = 0; t < SNT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[t][e];                                  // columns beyond N hold +inf
+                    const bool on = (tmw[t >> 3] >> ((t & 7) * 4 + e)) & 1u;
+                    mx = fmaxf(mx, d == INF ? 0.f : (on ? d : fill));
+                }
+            mx = row4_maxf(mx);
+        }
+        auto val = [&](int t, int e) -> float {              // the entry as the reference's masked matrix holds it
+            const float d = acc[t][e];
+            if (!masked) return d;
+            const bool on = (tmw[t >> 3] >> ((t & 7) * 4 + e)) & 1u;
+            return (on || d == INF) ? d : fill;
+        };
+
+        // ---- density: mean of the squares of the k smallest of the row (self included): MSB-first radix select on the bit pattern ---------------
+        float rho;
+        {
+            const int k = g.k;
+            unsigned T0 = 0;
+            bool done = false;
+            int top = 30;
+            if constexpr (!MASKED) {
+                if (k >= 2) {                              // the leading bits all of the row's values (the self-distance aside) share are decided without counting
+                    unsigned lo = 0xffffffffu, hi = 0u;
+                    const bool self_lane = g4 == (l15 >> 2);
+#pragma unroll
+                    for (int t = 0; t < SNT; ++t) {
+                        const bool ts = t == tself;         // wave-uniform
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned p0 = __float_as_uint(acc[t][e]);
+                            hi = max(hi, p0);
+                            if (ts) { if (self_lane && e == (l15 & 3)) p0 = 0xffffffffu; }
+                            lo = min(lo, p0);
+                        }
+                    }
+                    lo = row4_minu(lo); hi = row4_maxu(hi);
+                    const unsigned df = lo ^ hi;
+                    const int hb = df ? 31 - __builtin_clz(df) : -1;
+                    T0 = hb >= 0 ? (hb >= 31 ? 0u : lo & ~((2u << hb) - 1u)) : lo;
+                    top = 30;
+                    while (top > 0 && __ballot(hb >= top) == 0ull) --top;
+                }
+            }
+            for (int bit = top; bit >= 0; --bit) {
+                const unsigned c0 = T0 | (1u << bit);
+                int q = 0;
+#pragma unroll
+                for (int tp = 0; tp < SNT / 2; ++tp) {      // eight elements per count register, eighteen independent registers
+                    unsigned w0 = 0;
+#pragma unroll
+                    for (int t = tp * 2; t < tp * 2 + 2; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w0 = __builtin_amdgcn_alignbit(w0, __float_as_uint(val(t, e)) - c0, 31);
+                    q += __builtin_popcount(w0);
+                }
+                q = (int)row4_add((unsigned)q);
+                if (!done) { if (q <= k - 1) T0 = c0; else if (q == k) { T0 = c0; done = true; } }
+                if (__ballot(!done) == 0ull) break;
+            }
+            float s0 = 0.f; int q = 0;
+#pragma unroll
+            for (int t = 0; t < SNT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = val(t, e);
+                    const bool in0 = __float_as_uint(v0) < T0;
+                    s0 += in0 ? v0 * v0 : 0.f; q += in0;
+                }
+            s0 = row4_addf(s0);
+            q = (int)row4_add((unsigned)q);
+            const float kth = __uint_as_float(T0);
+            const float tie = q < k ? (float)(k - q) * (kth * kth) : 0.f;
+            rho = expf(-((s0 + tie) / (float)k));
+            if (g.noise && rvalid) rho += g.noise[(int64_t)b * N + row] * 1e-6f;
+            if (masked && !tm_row) rho = 0.f;                                  // density * token_mask (:94)
+            if (g4 == 0 && rvalid) { w_rho[row] = rho; w_rmax[row] = mx; }
+        }
+        // ---- exchange 1: every strip's rho / row max ---------------------------------------------------------------------------------------------
+        strip_publish(w_cnt + 1);
+        strip_wait(w_cnt + 1, S);
+        for (int i = tid; i < 640; i += 512) { s_rho[i] = i < N ? w_rho[i] : -1.0f; s_rmax[i] = i < N ? w_rmax[i] : INF; }
+        __syncthreads();
+
+        // ---- delta_i = min_j (rho_j > rho_i ? D_ij : rowmax_j) (:96-99), score = delta * rho (:101) -----------------------------------------------
+        {
+            float dm = INF;
+#pragma unroll
+            for (int t = 0; t < SNT; ++t) {
+                const f32x4 rj = *reinterpret_cast<const f32x4*>(s_rho + t * 16 + 4 * g4);
+                const f32x4 mj = *reinterpret_cast<const f32x4*>(s_rmax + t * 16 + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dm = fminf(dm, rj[e] > rho ? val(t, e) : mj[e]);
+            }
+            dm = row4_minf(dm);
+            if (g4 == 0 && rvalid) {
+                const float sc = dm * rho;
+                w_score[row] = sc;
+                g.score[(int64_t)b * N + row] = sc;
+            }
+        }
+        // ---- exchange 2: every strip's scores ------------------------------------------------------------------------------------------------------
+        strip_publish(w_cnt + 2);
+        strip_wait(w_cnt + 2, S);
+        for (int i = tid; i < 640; i += 512) s_score[i] = i < N ? w_score[i] : 0.f;
+        __syncthreads();
+
+        // ---- centres (:103-107): every workgroup of the image selects them itself (same inputs, same result) -------------------------------------
+        for (int i = tid; i < 640; i += 512) {
+            const unsigned long long bal = __ballot(i < N && s_score[i] > g.thr);
+            if (lane == 0) s_mask[i >> 6] = bal;
+        }
+        __syncthreads();
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int w = 0; w < 10; ++w) any |= s_mask[w];
+        const bool none = any == 0ull;                       // uniform
+        __syncthreads();
+        if (none) {                                          // the min_cluster_num largest scores, ties to the lower index, in index order
+            for (int i = tid; i < 640; i += 512) {
+                const float si = i < N ? s_score[i] : 0.f;
+                int rank = 0;
+                for (int j = 0; j < N; ++j) { const float sj = s_score[j]; rank += (sj > si) || (sj == si && j < i); }
+                const unsigned long long bal = __ballot(i < N && rank < g.mcn);
+                if (lane == 0) s_mask[i >> 6] = bal;
+            }
+        }
+        __syncthreads();
+        int L = 0;
+#pragma unroll
+        for (int w = 0; w < 10; ++w) L += __builtin_popcountll(s_mask[w]);
+        for (int i = tid; i < 640; i += 512) {
+            const int w = i >> 6;
+            const unsigned long long mine = s_mask[w];
+            int pos = __builtin_popcountll(mine & ((1ull << (i & 63)) - 1ull));
+            for (int v = 0; v < w; ++v) pos += __builtin_popcountll(s_mask[v]);
+            s_rank[i] = pos;
+            if (strip == 0) {
+                if ((mine >> (i & 63)) & 1ull) g.index_down[(int64_t)b * N + pos] = i;
+                if (i >= L && i < N) g.index_down[(int64_t)b * N + i] = -1;
+            }
+        }
+        if (strip == 0 && tid == 0) g.counts[b] = L;
+        __syncthreads();
+
+        // ---- assignment (:111-119): first argmin over the centres, read along the token's OWN row (the matrix is symmetric) ---------------------
+        {
+            float bd = INF; int code = 0x7fffffff;                               // code = 4 t + e: a literal per element, the column index is formed once at the end
+#pragma unroll
+            for (int t = 0; t < SNT; ++t) {
+                const unsigned nib = (unsigned)(s_mask[t >> 2] >> ((t & 3) * 16 + 4 * g4)) & 0xfu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool c = (nib >> e) & 1u;
+                    const float v0 = acc[t][e];                                  // D[centre][token] is the RAW distance when the token is unmasked
+                    if (c && v0 < bd) { bd = v0; code = 4 * t + e; }             // (ascending column order within the lane: the first minimum wins)
+                }
+            }
+            int jb = code == 0x7fffffff ? 0x7fffffff : (code >> 2) * 16 + 4 * g4 + (code & 3);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ob = __shfl_xor(bd, o, 64);
+                const int oj = __shfl_xor(jb, o, 64);
+                if (ob < bd || (ob == bd && oj < jb)) { bd = ob; jb = oj; }
+            }
+            if (g4 == 0 && rvalid) {
+                int lab = ((masked && !tm_row) || jb >= SN) ? 0 : s_rank[jb];
+                if ((s_mask[row >> 6] >> (row & 63)) & 1ull) lab = s_rank[row];    // a centre owns itself
+                g.idx[(int64_t)b * N + row] = lab;
+            }
+        }
+        __syncthreads();                                    // before the next item overwrites stage 0 and the item word
+    }
+}
+}  // namespace
+
 // |x_i|^2 = G_ii (the same fma chain as every other Gram entry) -> vec[b][3][i]
 __global__ void dpc_diag_kernel(const float* __restrict__ G, float* __restrict__ vec, int B, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -805,8 +1240,9 @@ static bool fused_disabled() {                      // SETOK_CLUSTER_FUSED=0: th
 extern "C" int setok_cluster_workspace(int dtype, int B, int N, int C, int64_t* dist_floats, int64_t* vec_floats) {
     SETOK_CHECK_ARG(dist_floats && vec_floats && B >= 0 && N > 0 && C > 0, "setok_cluster_workspace: bad argument");
     const bool fused = dtype == SETOK_BF16 && C % 64 == 0 && N <= FN && !fused_disabled();
-    *dist_floats = fused ? 0 : (int64_t)B * N * N;
-    *vec_floats = fused ? 0 : (int64_t)B * 4 * N;
+    const bool strips = dtype == SETOK_BF16 && C % 64 == 0 && N > FN && N <= SN && !fused_disabled();
+    *dist_floats = (fused || strips) ? 0 : (int64_t)B * N * N;                 // the N x N matrix exists in memory only on the multi-kernel path
+    *vec_floats = fused ? 0 : (strips ? (int64_t)S_HDR + (int64_t)B * S_IMG : (int64_t)B * 4 * N);
     return SETOK_OK;
 }
 
@@ -847,6 +1283,27 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
                 fprintf(stderr, "[cluster timing] B=%d N=%d C=%d  cycles of workgroup 0: gram %llu, distances %llu, density %llu, delta %llu, centres %llu, assignment %llu, total %llu\n",
                         B, N, C, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
         }
+        return SETOK_OK;
+    }
+    if (dtype == SETOK_BF16 && C % 64 == 0 && N > FN && N <= SN && !fused_disabled()) {
+        // 256 < N <= 576 (cfg4): one launch of a persistent grid, a workgroup per (image, 128-row strip), no N x N workspace
+        SETOK_CHECK_ARG(vec_ws, "setok_cluster_dpc_knn: this shape needs the vector workspace (setok_cluster_workspace)");
+        static SetokDeviceOnce once_s;
+        if (!once_s.run([] { return hipFuncSetAttribute((const void*)dpc_strip_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS) == hipSuccess &&
+                                    hipFuncSetAttribute((const void*)dpc_strip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS) == hipSuccess; }))
+            return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot raise the dynamic LDS limit");
+        const int strips = cdiv(N, SROWS);
+        if (hipMemsetAsync(vec_ws, 0, ((size_t)S_HDR + (size_t)B * S_IMG) * 4, s) != hipSuccess)             // queue heads + exchange counters
+            return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot clear the exchange workspace");
+        int ex = 0;
+        const float mant = frexpf(sqrtC, &ex);
+        SArgs a{(const bf16*)x, noise, token_mask, idx_cluster, score, index_down, counts, vec_ws, B, N, C, k, min_cluster_num, strips, threshold, sqrtC,
+                1.0f / sqrtC, mant == 0.5f ? 1 : 0};
+        int ncu = 256, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        const int grid = B * strips < ncu ? B * strips : ncu;          // persistent: never more workgroups than CUs (147 KiB of LDS each: one per CU, all co-resident)
+        if (token_mask) dpc_strip_kernel<true><<<grid, 512, S_LDS, s>>>(a); else dpc_strip_kernel<false><<<grid, 512, S_LDS, s>>>(a);
+        SETOK_CHECK_LAUNCH("setok_cluster_dpc_knn(strips)");
         return SETOK_OK;
     }
     SETOK_CHECK_ARG(dist_ws && vec_ws, "setok_cluster_dpc_knn: this shape needs the distance workspace (setok_cluster_workspace)");

@@ -529,7 +529,9 @@ def test_cluster_fused_needs_no_workspace_and_is_deterministic():
     _lib.call("setok_cluster_workspace", ops.BF16, 256, 256, 1024, ctypes.byref(nd), ctypes.byref(nv))
     assert nd.value == 0 and nv.value == 0                               # bf16, N <= 256: one launch, no distance matrix in memory
     _lib.call("setok_cluster_workspace", ops.BF16, 128, 576, 1024, ctypes.byref(nd), ctypes.byref(nv))
-    assert nd.value == 128 * 576 * 576 and nv.value == 128 * 4 * 576
+    assert nd.value == 0 and 0 < nv.value < 128 * 4 * 576 * 2            # 256 < N <= 576: one launch over 128-row strips, no N x N matrix either; a few vectors per image
+    _lib.call("setok_cluster_workspace", ops.BF16, 4, 729, 1152, ctypes.byref(nd), ctypes.byref(nv))
+    assert nd.value == 4 * 729 * 729                                        # N > 576 (27 x 27 patches): the multi-kernel path and its matrix
     _lib.call("setok_cluster_workspace", ops.F32, 2, 256, 1024, ctypes.byref(nd), ctypes.byref(nv))
     assert nd.value == 2 * 256 * 256
     xs = torch.stack([O.planted_features(256, 1024, 5 + i, seed=120 + i) for i in range(64)]).bfloat16().to(DEV).reshape(-1, 1024)
@@ -588,3 +590,74 @@ def test_linear_ln_rows_do_not_depend_on_the_kernel():
         for lo, n in ((0, 257), (5000, 771), (M - 300, 300)):
             small = ops.linear_ln(x[lo:lo + n].contiguous(), folded, stats[lo:lo + n].contiguous(), act=act)
             assert torch.equal(small, big[lo:lo + n]), (act, lo)
+
+
+# ---- 256 < N <= 576 (cfg4: 24 x 24 patches): the strip kernel — one launch, workgroups of one image exchanging rho / row max / scores ------------
+STRIP_CASES = [
+    # N, C, B, k, mcn, thr, noise, mask
+    (576, 1024, 3, 64, 64, 0.5, False, False),
+    (576, 1024, 3, 64, 64, 1e9, True, False),          # the top-min_cluster_num fallback
+    (576, 1024, 2, 8, 64, 0.3, False, True),           # token_mask: the global raw maximum is a third exchange
+    (576, 256, 21, 2, 5, 0.5, True, False),            # more images than one round of 8 queues x a few workgroups; k = 2
+    (400, 512, 4, 64, 32, 0.4, False, False),          # 20 x 20: columns and rows beyond N, a partial column tile (400 = 25 x 16)
+    (324, 768, 3, 324, 16, 0.5, False, True),          # 18 x 18: 324 = 20.25 column tiles, k = N, three strips (the last one 68 rows)
+    (257, 64, 5, 16, 300 - 257 + 1, 0.2, True, False), # the smallest N of this path
+]
+
+
+@pytest.mark.parametrize("N,C,B,k,mcn,thr,with_noise,with_mask", STRIP_CASES)
+def test_cluster_strips_equal_the_multi_kernel_form_and_the_oracle(N, C, B, k, mcn, thr, with_noise, with_mask):
+    g = torch.Generator().manual_seed(N * 7 + C + B)
+    m = 6
+    xs = []
+    for i in range(B):
+        gx = torch.Generator().manual_seed(700 + 13 * i + N)
+        cent = torch.randn(m + i % 5, C, generator=gx) * 2.0
+        xs.append(cent[torch.randint(0, cent.shape[0], (N,), generator=gx)] + 0.05 * torch.randn(N, C, generator=gx))
+    xs = torch.stack(xs).bfloat16()
+    noise = torch.rand(B, N, generator=g) if with_noise else None
+    mask = None
+    if with_mask:
+        mask = (torch.rand(B, N, generator=g) > 0.3).float()
+        mask[:, 0] = 1.0
+    assert os.environ.get("SETOK_CLUSTER_FUSED") is None
+    a = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, k, thr, mcn, noise, mask)
+    a2 = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, k, thr, mcn, noise, mask)
+    assert all(torch.equal(u, v) for u, v in zip(a, a2))                                     # run to run: identical bits
+    os.environ["SETOK_CLUSTER_FUSED"] = "0"
+    try:
+        bm = ops.cluster_dpc_knn(xs.to(DEV).reshape(-1, C), B, N, k, thr, mcn, noise, mask)
+    finally:
+        del os.environ["SETOK_CLUSTER_FUSED"]
+    idx, score, index_down, counts = a
+    wide = k == N
+    for i in range(B):
+        L = int(counts[i])
+        nz = None if noise is None else noise[i]
+        tm = None if mask is None else mask[i]
+        r = O.cluster_dpc_knn(xs[i].float(), k, thr, mcn, tm, nz)
+        sens = O.cluster_sensitivity(xs[i].float(), k, thr, mcn, tm, nz, ulps=4096.0 if wide else 64.0)
+        assert 1 <= L <= N and int(idx[i].max()) < L and int(idx[i].min()) >= 0 and bool((index_down[i, L:] == -1).all()) and bool(torch.isfinite(score[i]).all())
+        O.check_cluster_parity(index_down[i, :L].cpu(), idx[i].cpu(), r.index_down, r.idx_cluster, sens)
+        if not wide:
+            O.check_score(score[i].cpu(), sens)
+        if sens["centres_certain"]:                                                          # the two GPU forms select alike wherever the decision is certain
+            assert L == int(bm[3][i]) and torch.equal(index_down[i, :L], bm[2][i, :L])
+    one = ops.cluster_dpc_knn(xs[B - 1].to(DEV), 1, N, k, thr, mcn, None if noise is None else noise[B - 1:], None if mask is None else mask[B - 1:])
+    assert torch.equal(one[0][0], idx[B - 1]) and torch.equal(one[1][0], score[B - 1]) and int(one[3][0]) == int(counts[B - 1])    # image alone == in the batch
+
+
+def test_cluster_strips_full_batch_cfg4():
+    """cfg4's clustering call at full size (128 images x 576 tokens x 1024 channels = 640 (image, strip) items on a persistent grid of one
+    workgroup per CU): every image equal to the same image clustered alone (the exchanges never mix images up), twice the same bits."""
+    B, N, C = 128, 576, 1024
+    g = torch.Generator().manual_seed(1)
+    cent = torch.randn(40, C, generator=g) * 1.5
+    xs = (cent[torch.randint(0, 40, (B, N), generator=g)] + 0.2 * torch.randn(B, N, C, generator=g)).bfloat16().to(DEV)
+    a = ops.cluster_dpc_knn(xs.reshape(-1, C), B, N, 64, 0.125, 64)
+    b = ops.cluster_dpc_knn(xs.reshape(-1, C), B, N, 64, 0.125, 64)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    for i in (0, 1, 7, 8, 63, 126, 127):
+        one = ops.cluster_dpc_knn(xs[i], 1, N, 64, 0.125, 64)
+        assert torch.equal(one[0][0], a[0][i]) and torch.equal(one[1][0], a[1][i]) and torch.equal(one[2][0], a[2][i]) and int(one[3][0]) == int(a[3][i]), i
+    assert int(a[3].min()) >= 1 and int(a[0].max()) < int(a[3].max())

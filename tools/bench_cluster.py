@@ -6,7 +6,8 @@ import torch
 from setok_amd import ops
 
 for dt, B, N, C, k, fused in [(torch.bfloat16, 256, 256, 1024, 64, "1"), (torch.bfloat16, 256, 256, 1024, 64, "0"), (torch.bfloat16, 1, 256, 1024, 64, "1"),
-                              (torch.bfloat16, 128, 576, 1024, 64, "1"), (torch.float32, 256, 256, 1024, 64, "1")]:
+                              (torch.bfloat16, 128, 576, 1024, 64, "1"), (torch.bfloat16, 128, 576, 1024, 64, "0"), (torch.bfloat16, 16, 576, 1024, 64, "1"),
+                              (torch.bfloat16, 1, 576, 1024, 64, "1"), (torch.float32, 256, 256, 1024, 64, "1")]:
     os.environ["SETOK_CLUSTER_FUSED"] = fused          # "0": the multi-kernel form (distance matrix through memory)
     x = torch.randn(B * N, C, device="cuda").to(dt)
     for _ in range(3):
