@@ -488,33 +488,34 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 // wait counted.  Same arithmetic per output element as the main kernel (bias as accumulator init, ascending k, one bf16 rounding,
 // round-then-add residual): a row's result does not depend on which kernel produced it.
 // --------------------------------------------------------------------------------------------
-constexpr int TT = 64;                           // tail tile edge (M; and N of the default shape)
+constexpr int TT = 64;                           // tail tile edge of the default shape
 constexpr int TNS = 8;                           // stages of the default shape
-__host__ __device__ constexpr int tail_stage(int ttn) { return (TT + ttn) * TK * 2; }          // A 8 KiB + W 8 / 4 KiB
-__host__ __device__ constexpr int tail_lds(int ttn, int ns) { return ns * tail_stage(ttn) + 2560; }   // + bias row (+ LNK: row rstds, column / row fragments)
+__host__ __device__ constexpr int tail_stage(int ttm, int ttn) { return (ttm + ttn) * TK * 2; }                     // 64 x 64: A 8 KiB + W 8 KiB
+__host__ __device__ constexpr int tail_lds(int ttm, int ttn, int ns) { return ns * tail_stage(ttm, ttn) + 2560; }   // + bias row (+ LNK: row rstds, column / row fragments)
 
-// TTN: columns per tile (64, or 32 for problems with too few 64 x 64 tiles to occupy the chip: twice the workgroups, each streaming 3/4 of
-// the bytes); NS: pipeline stages (8, or 4 = 66 KiB so that TWO workgroups fit a CU when a launch has more tiles than CUs).  The arithmetic
-// per output element does not depend on either.
-template <int ACT, bool LNK = false, int TTN = 64, int NS = TNS>
+// TTM x TTN: rows x columns per tile — 64 x 64; 64 x 32 or 32 x 32 for launches with too few 64 x 64 tiles to occupy the chip (two / four times
+// the workgroups, each streaming 3/4 / 1/2 of the bytes: these launches are bound by the latency of one workgroup's K loop); NS: pipeline stages
+// (8, or 4 = 66 KiB so that TWO workgroups fit a CU when a launch has more tiles than CUs).  The arithmetic per output element does not depend on
+// any of them.
+template <int ACT, bool LNK = false, int TTM = 64, int TTN = 64, int NS = TNS>
 __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
-    constexpr int NJ = TTN / 32;                            // 16-column MFMA tiles per wave along N (wave = 32 rows x TTN / 2 columns)
-    constexpr int LPT = 2 + NJ;                             // LDS-DMA loads per lane per K-tile: 2 of A, TTN / 32 of W
-    constexpr int STG = tail_stage(TTN);
+    constexpr int NI = TTM / 32, NJ = TTN / 32;             // 16 x 16 MFMA tiles per wave (wave = TTM / 2 rows x TTN / 2 columns)
+    constexpr int LPT = NI + NJ;                            // LDS-DMA loads per lane per K-tile: TTM / 32 of A, TTN / 32 of W
+    constexpr int STG = tail_stage(TTM, TTN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
-    const int m0 = (blockIdx.x / g.tilesN) * TT, n0 = (blockIdx.x % g.tilesN) * TTN;
+    const int m0 = (blockIdx.x / g.tilesN) * TTM, n0 = (blockIdx.x % g.tilesN) * TTN;
     const int Mrt = g.m_dev ? min(g.M, __builtin_amdgcn_readfirstlane(*g.m_dev)) : g.M;
     if (m0 >= Mrt) return;                                  // a ragged stage's tiles beyond its device-side row count (before any barrier)
     float* sbias = reinterpret_cast<float*>(smem + NS * STG);
     if (tid < TTN) sbias[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
-    if constexpr (LNK) {                                    // sbias[64..127] row rstds, then the column fragments and the 64 row fragments (16 B each)
+    if constexpr (LNK) {                                    // sbias[64..127] row rstds, then the column fragments and the row fragments (16 B each)
         if (tid < 64) {
-            const float* st = g.ln_stats + 8 * (int64_t)min(m0 + tid, Mrt - 1);
+            const float* st = g.ln_stats + 8 * (int64_t)min(m0 + min(tid, TTM - 1), Mrt - 1);
             sbias[64 + tid] = st[4];
             if (tid < TTN) reinterpret_cast<f32x4*>(sbias + 128)[tid] = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)min(n0 + tid, g.N - 1));
             const f32x4 rf = {st[0], st[0], st[1], st[1]};        // compact (-mean hi, lo), (1 / rstd hi, lo) -> the 8 k-slots
@@ -522,9 +523,9 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
         }
     }
 
-    const bf16* a_src[2]; const bf16* b_src[NJ];
+    const bf16* a_src[NI]; const bf16* b_src[NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int p = i * 256 + tid, row = p >> 3, kc = (p & 7) ^ swz(row);
         a_src[i] = g.A + (int64_t)min(m0 + row, Mrt - 1) * g.lda + kc * 8;
     }
@@ -543,13 +544,13 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
         const unsigned sb = lds0 + (kt % NS) * STG;
         const int k0 = kt * TK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(a_src[i] + k0, sb + i * 4096);
+        for (int i = 0; i < NI; ++i) dma16(a_src[i] + k0, sb + i * 4096);
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) dma16(b_src[i] + k0, sb + TT * TK * 2 + i * 4096);
+        for (int i = 0; i < NJ; ++i) dma16(b_src[i] + k0, sb + TTM * TK * 2 + i * 4096);
     };
     for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) issue(kt);
 
-    f32x4 acc[2][NJ];                                       // this wave's 32 x (TTN / 2): 2 x NJ MFMA tiles of 16 x 16
+    f32x4 acc[NI][NJ];                                      // this wave's (TTM / 2) x (TTN / 2): NI x NJ MFMA tiles of 16 x 16
     for (int kt = 0; kt < nk; ++kt) {
         // K-tile kt has landed for this wave: at most the LPT * min(NS - 2, nk - 1 - kt) younger loads may still fly
         switch (min(NS - 2, nk - 1 - kt)) {
@@ -572,8 +573,8 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) cfr[j] = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 128)[wn * (TTN / 2) + j * 16 + l15], g4);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bf16x8 rfr = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 384)[wm * 32 + t * 16 + l15], g4);
+                for (int t = 0; t < NI; ++t) {
+                    const bf16x8 rfr = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 384)[wm * (TTM / 2) + t * 16 + l15], g4);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
                 }
@@ -583,18 +584,19 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float b = sbias[wn * (TTN / 2) + j * 16 + 4 * g4 + e];
-                        acc[0][j][e] = b; acc[1][j][e] = b;
+#pragma unroll
+                        for (int t = 0; t < NI; ++t) acc[t][j][e] = b;
                     }
             }
         }
         const char* Ab = smem + (kt % NS) * STG;
-        const char* Bb = Ab + TT * TK * 2;
+        const char* Bb = Ab + TTM * TK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[NJ], af[2];
+            bf16x8 wf[NJ], af[NI];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ra = wm * 32 + t * 16 + l15;
+            for (int t = 0; t < NI; ++t) {
+                const int ra = wm * (TTM / 2) + t * 16 + l15;
                 af[t] = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 4 + g4) ^ swz(ra)) << 4));
             }
 #pragma unroll
@@ -603,38 +605,40 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
                 wf[j] = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 4 + g4) ^ swz(rb)) << 4));
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NI; ++t)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[t], acc[t][j], 0, 0, 0);
         }
     }
-    // epilogue: the 64 x TTN tile is transposed through stage 0 (every load has landed; the barrier orders the last reads); rows of 2 * TTN bytes
+    // epilogue: the TTM x TTN tile is transposed through stage 0 (every load has landed; the barrier orders the last reads); rows of 2 * TTN bytes
     s_barrier_lgkm();
     char* stg = smem;
     constexpr int RB = TTN * 2, NSL = TTN / 8;              // bytes / 16-byte slots per staged row
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NI; ++t)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             bf16x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[t][j][e];
-                if constexpr (LNK) x *= sbias[64 + wm * 32 + t * 16 + l15];
+                if constexpr (LNK) x *= sbias[64 + wm * (TTM / 2) + t * 16 + l15];
                 if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
                 else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
                 v[e] = (bf16)x;
             }
-            const int row = wm * 32 + t * 16 + l15;                 // columns wn * TTN / 2 + j * 16 + 4 * g4 .. + 3
+            const int row = wm * (TTM / 2) + t * 16 + l15;          // columns wn * TTN / 2 + j * 16 + 4 * g4 .. + 3
             const int sl = wn * (NSL / 2) + j * 2 + (g4 >> 1);
             *reinterpret_cast<bf16x4*>(stg + row * RB + ((sl ^ (row & (NSL - 1))) << 4) + 8 * (g4 & 1)) = v;
         }
     s_barrier_lgkm();
     const int slot = tid & (NSL - 1), col = n0 + slot * 8;
     constexpr int RPP = 256 / NSL;                          // rows per pass of the 256 threads
+    constexpr int PASSES = TTM > RPP ? TTM / RPP : 1;
 #pragma unroll
-    for (int it = 0; it < TT / RPP; ++it) {
+    for (int it = 0; it < PASSES; ++it) {
         const int row = it * RPP + tid / NSL;
+        if (row >= TTM) continue;
         const int grow = m0 + row;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * RB + ((slot ^ (row & (NSL - 1))) << 4));
         if (grow < Mrt && col < g.N && !(g.dbg & 1)) {
@@ -648,48 +652,50 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     }
 }
 
-// Shape of the small-tile launch for a problem (host side).  64 x 64 tiles with eight stages is the default (the M-tail of the persistent kernel
-// always uses it).  Whole small problems: fewer than half a chip of 64 x 64 tiles -> 64 x 32 tiles (twice the workgroups); more tiles than CUs but
-// fewer than two rounds -> four stages (66 KiB), so that two workgroups share a CU and the launch is ONE round.  SETOK_GEMM_SMALL_SHAPE=0 keeps the
-// default everywhere (A/B runs).
-struct TailShape { int ttn, ns; };
-static TailShape tail_shape_for(int M, int N, int ncu, bool whole_problem) {
+// Shape of the small-tile launch for a problem of M x N outputs (host side): how many workgroups the default 64 x 64 tiles give against the CUs.
+// SETOK_GEMM_SMALL_SHAPE=0 keeps the default everywhere (A/B runs).
+struct TailShape { int ttm, ttn, ns; };
+static TailShape tail_shape_for(int M, int N, int ncu) {
     static const bool off = [] { const char* e = getenv("SETOK_GEMM_SMALL_SHAPE"); return e && e[0] == '0'; }();
-    if (!whole_problem || off) return {64, TNS};
+    if (off) return {64, 64, TNS};
     const int t64 = cdiv(M, TT) * cdiv(N, 64);
-    if (t64 * 2 <= ncu && N % 32 == 0) return {32, TNS};
-    if (t64 > ncu && t64 <= 2 * ncu) return {64, 4};
-    return {64, TNS};
+    if (t64 * 4 <= ncu && N % 32 == 0) return {32, 32, TNS};          // a quarter of the chip: four times the workgroups
+    if (t64 * 2 <= ncu && N % 32 == 0) return {64, 32, TNS};          // half the chip: twice the workgroups
+    if (t64 > ncu && t64 <= 2 * ncu) return {64, 64, 4};              // between one and two rounds: two workgroups per CU, ONE round
+    return {64, 64, TNS};
 }
 
-template <int TTN, int NS>
+template <int TTM, int TTN, int NS>
 static int launch_tail_shape(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1) {
     static SetokDeviceOnce once;
     if (!once.run([] {
             bool ok = true;
-            const void* fns[] = {(const void*)gemm_tail_kernel<0, false, TTN, NS>, (const void*)gemm_tail_kernel<1, false, TTN, NS>, (const void*)gemm_tail_kernel<2, false, TTN, NS>,
-                                 (const void*)gemm_tail_kernel<0, true, TTN, NS>, (const void*)gemm_tail_kernel<1, true, TTN, NS>, (const void*)gemm_tail_kernel<2, true, TTN, NS>};
-            for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(TTN, NS)) == hipSuccess;
+            const void* fns[] = {(const void*)gemm_tail_kernel<0, false, TTM, TTN, NS>, (const void*)gemm_tail_kernel<1, false, TTM, TTN, NS>,
+                                 (const void*)gemm_tail_kernel<2, false, TTM, TTN, NS>, (const void*)gemm_tail_kernel<0, true, TTM, TTN, NS>,
+                                 (const void*)gemm_tail_kernel<1, true, TTM, TTN, NS>, (const void*)gemm_tail_kernel<2, true, TTM, TTN, NS>};
+            for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(TTM, TTN, NS)) == hipSuccess;
             return ok; }))
         return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
-    constexpr int LDS = tail_lds(TTN, NS);
+    constexpr int LDS = tail_lds(TTM, TTN, NS);
     const int grid = g.tilesM * g.tilesN;
     const dim3 gr(grid), bl(256);
     if (g.ln_stats) {
-        if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, true, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-        else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, true, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-        else setok_launch(gemm_tail_kernel<2, true, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-    } else if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, false, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-    else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, false, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-    else setok_launch(gemm_tail_kernel<2, false, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        else setok_launch(gemm_tail_kernel<2, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+    } else if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, false, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+    else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, false, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+    else setok_launch(gemm_tail_kernel<2, false, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
     SETOK_CHECK_LAUNCH("setok_linear(tail)");
     return SETOK_OK;
 }
 
-int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1, TailShape sh = {64, TNS}) {
-    if (sh.ttn == 32) return launch_tail_shape<32, TNS>(s, g, act, e0, e1);
-    if (sh.ns == 4) return launch_tail_shape<64, 4>(s, g, act, e0, e1);
-    return launch_tail_shape<64, TNS>(s, g, act, e0, e1);
+// g.tilesM / g.tilesN must have been computed for `sh` (cdiv(M, sh.ttm), cdiv(N, sh.ttn)).
+int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1, TailShape sh) {
+    if (sh.ttm == 32) return launch_tail_shape<32, 32, TNS>(s, g, act, e0, e1);
+    if (sh.ttn == 32) return launch_tail_shape<64, 32, TNS>(s, g, act, e0, e1);
+    if (sh.ns == 4) return launch_tail_shape<64, 64, 4>(s, g, act, e0, e1);
+    return launch_tail_shape<64, 64, TNS>(s, g, act, e0, e1);
 }
 
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0, hipEvent_t e1) {
@@ -790,18 +796,19 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     }
     if (rc != SETOK_OK || p == 0) return rc;
     const int m_off = tm_main * TM;
+    const TailShape sh = tail_shape_for(M - m_off, N, ncu);          // the remainder rows: a launch of its own, far from filling the chip
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,
-            lda, ldc, M - m_off, N, K, cdiv(M - m_off, TT), cdiv(N, TT), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1,
+            lda, ldc, M - m_off, N, K, cdiv(M - m_off, sh.ttm), cdiv(N, sh.ttn), dbg, nullptr, nullptr, nullptr, 0, 0, 0, 1,
             ln_stats ? ln_stats + 8 * (int64_t)m_off : nullptr, ln_colsum, nullptr};
-    return launch_tail(s, t, act, has_main ? nullptr : setok_prof_start_event(), setok_prof_stop_event());
+    return launch_tail(s, t, act, has_main ? nullptr : setok_prof_start_event(), setok_prof_stop_event(), sh);
 }
 
 // Called by setok_linear for SMALL bf16 -> bf16 problems (a handful of images: too few 128 x 128 tiles to fill 256 CUs): the deep-pipelined
 // 64 x 64 kernel over the whole problem.
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                           bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev) {
-    const TailShape sh = tail_shape_for(M, N, cu_count(), true);
-    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, TT), cdiv(N, sh.ttn), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum, m_dev};
+    const TailShape sh = tail_shape_for(M, N, cu_count());
+    PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, sh.ttm), cdiv(N, sh.ttn), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum, m_dev};
     const hipEvent_t e0 = setok_prof_start_event();
     return launch_tail(s, t, act, e0, setok_prof_stop_event(), sh);
 }
