@@ -29,7 +29,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int TM = 256, TK = 64, STAGE = 64 * 1024, BOFF = 32 * 1024, QT = 16 * 1024;
 __device__ inline int swz(int row) { return (row >> 1) & 7; }
 
-struct Args { const bf16* A; const bf16* W; bf16* C; int M, N, K, tilesM, tilesN; };
+struct Args { const bf16* A; const bf16* W; bf16* C; int M, N, K, tilesM, tilesN; unsigned long long* tim; };
 
 template <int GRP>
 __device__ __forceinline__ void body(const Args& g, char* smem, int m0, int n0) {
@@ -71,80 +71,139 @@ __device__ __forceinline__ void body(const Args& g, char* smem, int m0, int n0) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][j][e] = 0.f;
 
-    // fragment reads of one quadrant-half for both k-steps
-    bf16x8 af[2][4], wf[2][2];                                      // [k-step][row tile] / [k-step][column tile]
-    auto load_a = [&](const char* T, int ih) {
+    // fragments: both row halves and both column halves have registers of their own (96), so that the reads spread evenly over the phases:
+    //   load slot 0: W0 (4) + A0[k-step 0] (4)      MFMA slot 0 starts with the 4 reads of A0[k-step 1] (they land under its first 8 MFMAs)
+    //   load slot 1: W1 (4) + A1[k-step 0] (4)      load slot 2: A1[k-step 1] (4)      load slot 3: none
+    bf16x8 A0[2][4], A1[2][4], W0[2][2], W1[2][2];                  // [k-step][tile]
+    auto rd_a = [&](const char* T, int ih, int ks, bf16x8 (&dst)[4]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = GRP * 128 + ih * 64 + t * 16 + l15;
-                af[ks][t] = *reinterpret_cast<const bf16x8*>(T + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
-            }
+        for (int t = 0; t < 4; ++t) {
+            const int r = GRP * 128 + ih * 64 + t * 16 + l15;
+            dst[t] = *reinterpret_cast<const bf16x8*>(T + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
+        }
     };
-    auto load_w = [&](const char* T, int jh) {
+    auto rd_w = [&](const char* T, int jh, bf16x8 (&dst)[2][2]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = wc * 64 + jh * 32 + j * 16 + l15;
-                wf[ks][j] = *reinterpret_cast<const bf16x8*>(T + BOFF + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
+                dst[ks][j] = *reinterpret_cast<const bf16x8*>(T + BOFF + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
             }
     };
-    auto mma = [&](int ih, int jh) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+    auto mma8 = [&](int ih, int jh, const bf16x8 (&a)[4], const bf16x8 (&w)[2]) {      // one k-step of a quadrant
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[ih * 4 + t][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][t], acc[ih * 4 + t][jh * 2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; ++j)
+                acc[ih * 4 + t][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a[t], acc[ih * 4 + t][jh * 2 + j], 0, 0, 0);
     };
+    auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+#ifdef PP_TIMING
+    unsigned long long tw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per slot of the K-tile: cycles of work / at the barrier
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    int slot_id = 0;
+    auto bar = [&]() {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        tw[slot_id & 7] += t1 - tlast; tb[slot_id & 7] += t2 - t1; tlast = t2; ++slot_id;
+    };
+#else
     auto bar = [&]() { asm volatile("s_barrier" ::: "memory"); };
+#endif
 
-    // ---- prologue: K-tile 0 entirely + A_lo(1); the first read needs K-tile 0 -------------------------------------------------------------------
-    issue_quarter(0, 0); issue_quarter(1, 0); issue_quarter(2, 0); issue_quarter(3, 0); issue_quarter(0, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: K-tiles 0 and 1 entirely; the first read needs K-tile 0 -----------------------------------------------------------------------
+    // Requests per K-tile t from here on, all for K-tile t + 2 into the CURRENT stage s = t & 1, each pair in a light load slot:
+    //   phase 2: W_lo, W_hi(t+2)   (this stage's W quarters are free once phase 1's reads have retired; W0 stays in registers for phase 3)
+    //   phase 3: A_lo, A_hi(t+2)   (its A quarters once phase 2's have)
+    // so every quarter has a whole K-tile (>= 9 slots, ~1.2 us: the LDS-DMA round trip under load is ~1 us) to land, the heavy load slots
+    // (phases 0 and 1: 8 fragment reads each) carry no request at all, and the one wait of a K-tile is a counted vmcnt(8).
+#ifdef PP_CLUSTER
+    issue_quarter(0, 0); issue_quarter(1, 0); issue_quarter(2, 0); issue_quarter(3, 0);
+    issue_quarter(2, 1); issue_quarter(3, 1); issue_quarter(0, 1); issue_quarter(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    // SPREAD (kept): one quarter per phase — phase 0: A_lo(t+1) -> s^1, phase 1: A_hi(t+1) -> s^1, phase 2: W_lo(t+2) -> s, phase 3: W_hi(t+2) -> s;
+    // the wait is vmcnt(4).  (CLUSTER — both W quarters in phase 2, both A quarters in phase 3, a whole K-tile of flight, vmcnt(8) — measured
+    // 20 % SLOWER on all-zero operands: four requests in one slot hold the wave ~100 cycles each, and the K-tile period is bound by the per-CU
+    // LDS-DMA rate (~57 GB/s), not by the request latency.)
+    issue_quarter(0, 0); issue_quarter(1, 0); issue_quarter(2, 0); issue_quarter(3, 0); issue_quarter(2, 1); issue_quarter(3, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     bar();
     if (GRP == 1) bar();                                            // the second wave row runs one slot behind
+#ifdef PP_TIMING
+    slot_id = 0; tlast = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; ++i) { tw[i] = 0; tb[i] = 0; }
+#endif
 
     for (int kt = 0; kt < nk; ++kt) {
         const char* T = smem + (kt & 1) * STAGE;
-        const bool more = kt + 1 < nk;                              // K-tile kt + 1 exists: its quarters / the wait for them
         // phase 0
-        issue_quarter(1, kt + 1);
-        load_w(T, 0); load_a(T, 0);
+#ifndef PP_CLUSTER
+        issue_quarter(0, kt + 1);
+#endif
+        rd_w(T, 0, W0); rd_a(T, 0, 0, A0[0]);
         bar();
-        mma(0, 0);
+        rd_a(T, 0, 1, A0[1]);                                       // lands under the first 8 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");          // everything but those 4
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma8(0, 0, A0[0], W0[0]);
+        lgk0();
+        mma8(0, 0, A0[1], W0[1]);
+        __builtin_amdgcn_s_setprio(0);
         bar();
         // phase 1
-        issue_quarter(2, kt + 1);
-        load_w(T, 1);
+#ifndef PP_CLUSTER
+        issue_quarter(1, kt + 1);
+#endif
+        rd_w(T, 1, W1); rd_a(T, 1, 0, A1[0]);
+        lgk0();                                                     // the last readers of this stage's W quarters retire BEFORE the barrier: phase 2 refills them
         bar();
-        mma(0, 1);
+        __builtin_amdgcn_s_setprio(1);
+        mma8(0, 1, A0[0], W1[0]);
+        mma8(0, 1, A0[1], W1[1]);
+        __builtin_amdgcn_s_setprio(0);
         bar();
         // phase 2
-        issue_quarter(3, kt + 1);
-        load_a(T, 1);
+#ifdef PP_CLUSTER
+        issue_quarter(2, kt + 2); issue_quarter(3, kt + 2);
+#else
+        issue_quarter(2, kt + 2);
+#endif
+        rd_a(T, 1, 1, A1[1]);
+        lgk0();                                                     // likewise the A quarters: phase 3 refills them
         bar();
-        mma(1, 1);
+        __builtin_amdgcn_s_setprio(1);
+        mma8(1, 1, A1[0], W1[0]);
+        mma8(1, 1, A1[1], W1[1]);
+        __builtin_amdgcn_s_setprio(0);
         bar();
         // phase 3: the wait for K-tile kt + 1 sits one slot before its first reader (wave row 0 reads at the next slot boundary):
         //          row 0 waits at the end of its MFMA slot, row 1 at the end of its LOAD slot — the same barrier for both
-        issue_quarter(0, kt + 2);
-        load_w(T, 0);
-        if (GRP == 1) { if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifdef PP_CLUSTER
+        issue_quarter(0, kt + 2); issue_quarter(1, kt + 2);
+#define PP_WAIT "s_waitcnt vmcnt(8)"
+#else
+        issue_quarter(3, kt + 2);
+#define PP_WAIT "s_waitcnt vmcnt(4)"
+#endif
+        if (GRP == 1) { if (kt + 2 < nk) asm volatile(PP_WAIT ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         bar();
-        mma(1, 0);
-        if (GRP == 0) { if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_setprio(1);
+        mma8(1, 0, A1[0], W0[0]);
+        mma8(1, 0, A1[1], W0[1]);
+        __builtin_amdgcn_s_setprio(0);
+        if (GRP == 0) { if (kt + 2 < nk) asm volatile(PP_WAIT ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         bar();
-        (void)more;
     }
+#ifdef PP_TIMING
+    if (g.tim && blockIdx.x == 0 && (threadIdx.x & 255) == 0)
+        for (int i = 0; i < 8; ++i) { g.tim[GRP * 16 + i] = tw[i]; g.tim[GRP * 16 + 8 + i] = tb[i]; }
+#endif
     if (GRP == 0) bar();                                            // matches the second row's last barrier
 
     // ---- epilogue (plain): a lane holds row l15 of each 16-row tile, 4 consecutive columns per accumulator -> 8-byte stores ------------------
@@ -184,13 +243,16 @@ static void run(int M, int N, int K, double seconds) {
     std::vector<bf16> hA((size_t)M * K), hW((size_t)N * K);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto& v : hA) v = (bf16)rnd();
+    const bool zeros = getenv("GEMM_PP_ZEROS") != nullptr;        // all-zero operands: the clock is not power-managed down, cycles show
+    for (auto& v : hA) v = (bf16)(zeros ? 0.f : rnd());
     const float ws = 1.0f / sqrtf((float)K);
-    for (auto& v : hW) v = (bf16)(rnd() * ws * 1.7f);
+    for (auto& v : hW) v = (bf16)(zeros ? 0.f : rnd() * ws * 1.7f);
     bf16 *dA, *dW, *dC;
     CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dC, (size_t)M * N * 2));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
-    Args g{dA, dW, dC, M, N, K, (M + 255) / 256, (N + 255) / 256};
+    unsigned long long* dT = nullptr;
+    CK(hipMalloc(&dT, 32 * 8)); CK(hipMemset(dT, 0, 32 * 8));
+    Args g{dA, dW, dC, M, N, K, (M + 255) / 256, (N + 255) / 256, dT};
     CK(hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
     const int grid = g.tilesM * g.tilesN;
     gemm_pp_kernel<<<grid, 512, 2 * STAGE>>>(g);
@@ -216,6 +278,20 @@ static void run(int M, int N, int K, double seconds) {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float t; CK(hipEventElapsedTime(&t, e0, e1)); ms = t / 20;
     }
+#ifdef PP_TIMING
+    {
+        unsigned long long h[32];
+        CK(hipMemcpy(h, dT, sizeof(h), hipMemcpyDeviceToHost));
+        const double nkt = K / 64.0;
+        static const char* names[8] = {"load0", "mma0", "load1", "mma1", "load2", "mma2", "load3", "mma3"};
+        for (int gq = 0; gq < 2; ++gq) {
+            printf("  row %d cycles per K-tile (work + barrier wait):", gq);
+            double tot = 0;
+            for (int i = 0; i < 8; ++i) { printf(" %s %.0f+%.0f", names[i], h[gq * 16 + i] / nkt, h[gq * 16 + 8 + i] / nkt); tot += (h[gq * 16 + i] + h[gq * 16 + 8 + i]) / nkt; }
+            printf("  = %.0f\n", tot);
+        }
+    }
+#endif
     printf("gemm_pp M=%d N=%d K=%d: %8.1f us  %7.1f TF   worst sampled rel err %.2e %s\n", M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, worst,
            worst < 2e-2 ? "OK" : "WRONG");
     fflush(stdout);
