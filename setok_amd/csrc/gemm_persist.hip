@@ -698,6 +698,337 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
     return launch_tail_shape<64, 64, TNS>(s, g, act, e0, e1);
 }
 
+// --------------------------------------------------------------------------------------------
+// The PING-PONG form of the persistent kernel (round 3) — same tiles, same LDS image, same fragment / accumulator layout, same arithmetic per
+// output element (the results are bit-identical to gemm_persist_kernel's), a different SCHEDULE of the K loop:
+//   * a K-tile is four phases per wave — the quadrants (row half i, column half j) of its 128 x 64 output in the order (0,0) (0,1) (1,1) (1,0) —
+//     each a LOAD slot (fragment reads, one quarter-tile of LDS-DMA requests) and an MFMA slot (16 MFMAs), every slot closed by s_barrier;
+//   * the two wave rows run ONE SLOT APART (waves 4-7 execute one extra barrier first): on every SIMD one wave multiplies while its partner reads
+//     fragments and stands at the address unit — the matrix pipe never has two claimants, and the lock-step in which gemm_persist_kernel's two
+//     waves of a SIMD both fetch and then both multiply (matrix pipe busy 47 % of a launch) is gone by construction;
+//   * operands arrive in QUARTER tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255 of a stage: 16 KiB = 2 requests per lane, full 128-byte
+//     rows), one quarter per phase: phase 0: A_lo(t+1), phase 1: A_hi(t+1), phase 2: W_lo(t+2), phase 3: W_hi(t+2) — a quarter of the current stage
+//     is refilled as soon as its last reader of this K-tile has retired (W after phase 1: the column fragments of phase 3 stay in registers;
+//     A after phase 2) — and the stream runs across tile boundaries; the one wait of a K-tile is a counted vmcnt one slot before the next
+//     K-tile's first reader.  The A quarters of a tile's SECOND K-tile go out before the previous tile's stores, so no request queues behind a store.
+// Same-box A/B against gemm_persist_kernel (tools/micro/gemm_pp2.hip, plain GEMM, random operands): 65792 x 3072 x 1024 +7 %, 65792 x 4096 x 1024
+// +10 %, 8192^3 +3 %; on all-zero operands (clock not power-managed) +19 % / +15 % / +18 %: at 1.8 PFLOP/s the K-tile period is the per-CU LDS-DMA
+// rate (64 KiB per ~1.1 us).  Used for launches without a residual and with N a multiple of 256 (q|k|v, fc1, the head's / projector's plain
+// Linears); the residual launches stay on gemm_persist_kernel (no gain at K = 4096, and no registers for the residual rows beside 96 fragment
+// registers).  SETOK_GEMM_PP=0 switches it off (A/B runs).
+// --------------------------------------------------------------------------------------------
+#ifndef PP_NO_EDGE
+#define PP_NO_EDGE 1        // 1: the host hands this kernel whole 256-row tiles only (the remainder rows go to the small-tile kernel, a device-side M to gemm_persist_kernel)
+#endif
+template <int ACT, bool LNK, int GRP>
+__device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
+    constexpr int QT = 16 * 1024;
+    constexpr int NSTORE = 16;
+    constexpr int NAUX = LNK ? 5 : 4;                       // ordinary loads per lane per tile in the middle of the epilogue (next tile's bias / LN fragments)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3;                                // wave row == GRP
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int nk = g.K / TK;
+    const int Mrt = (!PP_NO_EDGE && g.m_dev) ? min(g.M, __builtin_amdgcn_readfirstlane(*g.m_dev)) : g.M;
+    const int tilesMrt = (!PP_NO_EDGE && g.m_dev) ? (Mrt + TM - 1) / TM : g.tilesM;
+    const int num_tiles = tilesMrt * g.tilesN;
+    const int G = gridDim.x;
+    auto tile_of = [&](int round, int& m0, int& n0) -> bool {
+        int L;
+        if ((G & 7) == 0) L = round * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        else L = round * G + blockIdx.x;
+        if (L >= num_tiles) return false;
+        constexpr int GM = 8;
+        const int per = GM * g.tilesN, group = L / per, first_m = group * GM;
+        const int gm = min(tilesMrt - first_m, GM), in = L - group * per;
+        m0 = (first_m + in % gm) * TM;
+        n0 = (in / gm) * 256;
+        return true;
+    };
+    // LDS-DMA source: piece p = 512 i + tid of a quarter -> row 64 i + (tid >> 3), 16-byte slot (tid & 7) ^ swizzle(row); the swizzle does not
+    // depend on i, so ONE lane offset per operand serves every piece and the row advance goes into the wave-uniform base.  Only a tile that
+    // crosses the end of M clamps rows (per-lane offsets formed on the fly there).
+    const int prow = tid >> 3;
+    const unsigned kc16 = (unsigned)(((tid & 7) ^ swz(prow)) << 4);
+    const unsigned a_off = (unsigned)prow * (unsigned)(g.lda * 2) + kc16;
+    const unsigned w_off = (unsigned)prow * (unsigned)(g.K * 2) + kc16;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
+    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
+        unsigned keep;
+        const unsigned long long b64 = (unsigned long long)base;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+        const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
+    };
+    int m0, n0, nm0 = 0, nn0 = 0, round = 0;
+    if (!tile_of(0, m0, n0)) return;
+    bool has_next = tile_of(1, nm0, nn0);
+    int cnt = 0;                                            // K-tiles consumed before this tile: K-tile u of the tile lives in stage (cnt + u) & 1
+    // Per tile, once: the byte addresses of its first A row / first W row (wave-uniform 64-bit values) and whether it crosses the end of M; a
+    // request then costs a handful of scalar adds (computed per request from m0 / n0 the 64-bit multiplies were ~35 scalar instructions each,
+    // eight times per K-tile, inside the load slots).
+    const size_t a_half = (size_t)128 * (size_t)(g.lda * 2), a_piece = (size_t)64 * (size_t)(g.lda * 2);
+    const size_t w_half = (size_t)128 * (size_t)(g.K * 2), w_piece = (size_t)64 * (size_t)(g.K * 2);
+    const char *a_cur, *w_cur, *a_nxt = nullptr, *w_nxt = nullptr;
+    bool edge_cur, edge_nxt = false;
+    int lim_cur, lim_nxt = 0;                               // last valid row inside an edge tile
+    auto tile_ptrs = [&](int tm0, int tn0, const char*& a, const char*& w, bool& edge, int& lim) {
+        a = reinterpret_cast<const char*>(g.A + (int64_t)tm0 * g.lda);
+        w = reinterpret_cast<const char*>(g.W + (int64_t)tn0 * g.K);
+        edge = tm0 + TM > Mrt;
+        lim = Mrt - 1 - tm0;
+    };
+    tile_ptrs(m0, n0, a_cur, w_cur, edge_cur, lim_cur);
+    if (has_next) tile_ptrs(nm0, nn0, a_nxt, w_nxt, edge_nxt, lim_nxt);
+    // quarter q (0 = A_lo, 1 = A_hi, 2 = W_lo, 3 = W_hi) of K-tile u (< nk) of a tile given by its pointers -> stage `stage`
+    auto issue_at = [&](int q, int u, int stage, const char* at, const char* wt, bool edge, int lim) {
+        const unsigned sb = lds0 + stage * STAGE + (q >> 1) * BOFF + (q & 1) * QT;
+        if (q >> 1) {
+            const char* base = wt + (q & 1) * w_half + (size_t)u * 128;
+            dma16(base, w_off, sb);
+            dma16(base + w_piece, w_off, sb + 8192);
+        } else if (PP_NO_EDGE || !edge) {
+            const char* base = at + (q & 1) * a_half + (size_t)u * 128;
+            dma16(base, a_off, sb);
+            dma16(base + a_piece, a_off, sb + 8192);
+        } else {                                            // the tile crosses the end of M: rows clamped to the last one (never stored)
+            const char* base = at + (size_t)u * 128;
+            const int r0 = (q & 1) * 128;
+            dma16(base, (unsigned)min(r0 + prow, lim) * (unsigned)(g.lda * 2) + kc16, sb);
+            dma16(base, (unsigned)min(r0 + 64 + prow, lim) * (unsigned)(g.lda * 2) + kc16, sb + 8192);
+        }
+    };
+    // ... of the CURRENT tile's K-tile u; u >= nk runs into the next tile's K-tile u - nk (the stream does not stop at tile boundaries)
+    auto issue_quarter = [&](int q, int u) {
+        if (u < nk) issue_at(q, u, (cnt + u) & 1, a_cur, w_cur, edge_cur, lim_cur);
+        else if (has_next) issue_at(q, u - nk, (cnt + u) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
+    };
+
+    f32x4 acc[8][4];
+    bf16x8 A0[2][4], A1[2][4], W0[2][2], W1[2][2];          // [k-step][tile]: both row halves and both column halves have registers of their own
+    auto rd_a = [&](const char* T, int ih, int ks, bf16x8 (&dst)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = GRP * 128 + ih * 64 + t * 16 + l15;
+            dst[t] = *reinterpret_cast<const bf16x8*>(T + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
+        }
+    };
+    auto rd_w = [&](const char* T, int jh, bf16x8 (&dst)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wn * 64 + jh * 32 + j * 16 + l15;
+                dst[ks][j] = *reinterpret_cast<const bf16x8*>(T + BOFF + r * 128 + (((ks * 4 + g4) ^ swz(r)) << 4));
+            }
+    };
+    auto mma8 = [&](int ih, int jh, const bf16x8 (&a)[4], const bf16x8 (&w)[2]) {      // one k-step of a quadrant
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[ih * 4 + t][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a[t], acc[ih * 4 + t][jh * 2 + j], 0, 0, 0);
+    };
+    auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    auto bar = [&]() { asm volatile("s_barrier" ::: "memory"); };
+
+    // what the accumulators of a tile start from: the bias (4 consecutive columns per accumulator register quad), or the folded LayerNorm's
+    // fragments (fetched exactly as gemm_persist_kernel fetches them: one column fragment, the compact form of two row fragments, two rstd)
+    f32x4 nbv[4];
+    f32x4 ncw; float2 nrw[2]; float nrs[2], ers[2];
+    auto load_start = [&](int n0_, int m0_) {
+        if constexpr (LNK) {
+            ncw = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)(n0_ + wn * 64 + g4 * 16 + l15));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* st = g.ln_stats + 8 * (int64_t)(PP_NO_EDGE ? m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15 : min(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15, Mrt - 1));
+                nrw[i] = *reinterpret_cast<const float2*>(st);
+                nrs[i] = st[4];
+            }
+        } else {
+            const float* bp = (g.bias ? g.bias + n0_ : g.zero_bias) + (g.bias ? wn * 64 : 0) + 4 * g4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nbv[j] = *reinterpret_cast<const f32x4*>(bp + (g.bias ? j * 16 : 0));
+        }
+    };
+
+    // ---- start of the stream: the first tile's start values, K-tile 0 entirely + the W quarters of K-tile 1 --------------------------------------
+    load_start(n0, m0);
+    issue_quarter(0, 0); issue_quarter(1, 0); issue_quarter(2, 0); issue_quarter(3, 0); issue_quarter(2, 1); issue_quarter(3, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    bar();
+    if (GRP == 1) bar();                                    // the second wave row runs one slot behind
+    int ahead = 0;                                          // 1: the A quarters of this tile's K-tile 1 went out in the previous tile's epilogue, ahead of
+                                                            // exactly NSTORE + NAUX other entries of the vector-memory queue; 2: ahead of an unknown number
+    for (;;) {
+        // ---- accumulator start --------------------------------------------------------------------------------------------------------------------
+        if constexpr (LNK) {
+            auto from_group = [&](float v, int grp) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l15 + 16 * grp) << 2, __builtin_bit_cast(int, v)));
+            };
+            bf16x8 cfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = from_group(ncw[e], j);
+                cfr[j] = ln_frag_lane(v, g4);
+            }
+            ers[0] = nrs[0]; ers[1] = nrs[1];
+            f32x4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float d0 = from_group(nrw[t & 1].x, t >> 1), d1 = from_group(nrw[t & 1].y, t >> 1);
+                const f32x4 v = {d0, d0, d1, d1};
+                const bf16x8 rfr = ln_frag_lane(v, g4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = nbv[j];          // bias first, then the products in ascending k: gemm_persist_kernel's order
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* T = smem + ((cnt + kt) & 1) * STAGE;
+            const bool skipA = ahead != 0 && kt == 0;        // (uniform)
+            // phase 0
+            if (!skipA) issue_quarter(0, kt + 1);
+            rd_w(T, 0, W0); rd_a(T, 0, 0, A0[0]);
+            bar();
+            rd_a(T, 0, 1, A0[1]);                           // lands under the first 8 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma8(0, 0, A0[0], W0[0]);
+            lgk0();
+            mma8(0, 0, A0[1], W0[1]);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            // phase 1
+            if (!skipA) issue_quarter(1, kt + 1);
+            rd_w(T, 1, W1); rd_a(T, 1, 0, A1[0]);
+            lgk0();                                         // the last readers of this stage's W quarters retire BEFORE the barrier: phase 2 refills them
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma8(0, 1, A0[0], W1[0]);
+            mma8(0, 1, A0[1], W1[1]);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            // phase 2
+            issue_quarter(2, kt + 2);
+            rd_a(T, 1, 1, A1[1]);
+            lgk0();                                         // likewise this stage's A quarters (refilled by the next K-tile's phases 0 / 1, or the epilogue)
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma8(1, 1, A1[0], W1[0]);
+            mma8(1, 1, A1[1], W1[1]);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            // phase 3 + the one wait of the K-tile, one slot before the next K-tile's first reader (wave row 0 reads at the next slot boundary:
+            // row 0 waits at the end of its MFMA slot, row 1 at the end of its LOAD slot — the same barrier for both)
+            issue_quarter(3, kt + 2);
+            const bool issued = kt + 2 < nk || has_next;    // the two W quarters of this K-tile's phases 2 / 3 exist
+            auto wait_next = [&]() {
+                if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (skipA && ahead == 1) wait_vm<4 + NSTORE + NAUX>();      // [A(1) quarters][stores, start-value loads][W(2) quarters]: only the first must have landed
+                else wait_vm<4>();
+            };
+            if (GRP == 1) wait_next();
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma8(1, 0, A1[0], W0[0]);
+            mma8(1, 0, A1[1], W0[1]);
+            __builtin_amdgcn_s_setprio(0);
+            if (GRP == 0) wait_next();
+            bar();
+        }
+        // ---- tile boundary ------------------------------------------------------------------------------------------------------------------------
+        cnt += nk;
+        const bool interior = PP_NO_EDGE || m0 + TM <= Mrt;
+        if (has_next) {                                     // the A quarters of the next tile's K-tile 1 -> the stage of the K-tile just finished, BEFORE the stores
+            issue_at(0, 1, (cnt + 1) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
+            issue_at(1, 1, (cnt + 1) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
+        }
+        {
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int slot = lane_e & 7, lrow = lane_e >> 3;
+            char* stg = smem + 2 * STAGE + wave * 4096;
+            char* c_wave = reinterpret_cast<char*>(g.C + (int64_t)(m0 + GRP * 128) * g.ldc + (n0 + wn * 64));
+            const unsigned lane_off = (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
+            const unsigned row8 = (unsigned)g.ldc * 16u;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float er_pass[2] = {1.f, 1.f};
+                if constexpr (LNK) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        er_pass[tt] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l15 + 16 * h) << 2, __builtin_bit_cast(int, ers[tt])));
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x4 v;
+                        f32x4 xs = acc[2 * h + tt][j];
+                        if constexpr (LNK) xs = xs * er_pass[tt];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = xs[e];
+                            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
+                            else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
+                            v[e] = (bf16)x;
+                        }
+                        const int srow = tt * 16 + l15;
+                        *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((j * 2 + (g4 >> 1)) ^ (srow & 7)) << 4) + 8 * (g4 & 1)) = v;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bf16x8 ov[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + lrow;
+                    ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
+                }
+                if (h == 2 && has_next) load_start(nn0, nm0);   // the next tile's start values: into registers the first two passes freed; NAUX queue entries
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int grow = m0 + GRP * 128 + h * 32 + it * 8 + lrow;
+                    if (interior || grow < Mrt)
+                        *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the staging rows are rewritten by the next pass)
+            }
+        }
+        if (!has_next) break;
+        ahead = interior ? 1 : 2;
+        m0 = nm0; n0 = nn0; ++round;
+        a_cur = a_nxt; w_cur = w_nxt; edge_cur = edge_nxt; lim_cur = lim_nxt;
+        has_next = tile_of(round + 1, nm0, nn0);
+        if (has_next) tile_ptrs(nm0, nn0, a_nxt, w_nxt, edge_nxt, lim_nxt);
+    }
+    if (GRP == 0) bar();                                    // matches the second row's last barrier
+}
+
+template <int ACT, bool LNK>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(PArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) gemm_pp_body<ACT, LNK, 0>(g, smem); else gemm_pp_body<ACT, LNK, 1>(g, smem);
+}
+
+static bool pp_enabled() {
+    static const bool on = [] { const char* e = getenv("SETOK_GEMM_PP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0, hipEvent_t e1) {
     static SetokDeviceOnce once;
     if (!once.run([] {
@@ -714,6 +1045,25 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
     const dim3 gr(grid), bl(512);
+    if (!res && !g.Cf && g.N % 256 == 0 && g.K >= 128 && !g.tim && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev))) {   // the ping-pong schedule (no residual, whole tiles)
+        static SetokDeviceOnce once_pp;
+        if (!once_pp.run([] {
+                bool ok = true;
+                const void* fns[] = {(const void*)gemm_pp_kernel<0, false>, (const void*)gemm_pp_kernel<1, false>, (const void*)gemm_pp_kernel<2, false>,
+                                     (const void*)gemm_pp_kernel<0, true>, (const void*)gemm_pp_kernel<1, true>, (const void*)gemm_pp_kernel<2, true>};
+                for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
+                return ok; }))
+            return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
+        if (g.ln_stats) {
+            if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
+            else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
+            else setok_launch(gemm_pp_kernel<2, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        } else if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        else setok_launch(gemm_pp_kernel<2, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        SETOK_CHECK_LAUNCH("setok_linear(ping-pong)");
+        return SETOK_OK;
+    }
     if (g.ln_stats) {
         if (act == SETOK_ACT_NONE) setok_launch(gemm_persist_kernel<0, false, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
         else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_persist_kernel<1, false, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
@@ -768,6 +1118,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 #endif
         return v;
     }();
+    if (p == 0 && M % TM != 0 && tilesM > 1 && !m_dev && !res && N % 256 == 0 && pp_enabled()) p = 1;   // the ping-pong kernel takes whole 256-row tiles only: the ragged last one goes to the small-tile kernel
     if (dbg & 4 || m_dev) p = 0;                                    // a device-side row count: no host-side split of M
     if (dbg & 8) p = tilesM;                                        // experiment: everything through the deep-pipeline 64x64 kernel
     const int tm_main = tilesM - p;
