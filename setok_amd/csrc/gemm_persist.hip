@@ -720,11 +720,14 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #ifndef PP_NO_EDGE
 #define PP_NO_EDGE 1        // 1: the host hands this kernel whole 256-row tiles only (the remainder rows go to the small-tile kernel, a device-side M to gemm_persist_kernel)
 #endif
-template <int ACT, bool LNK, int GRP>
+template <int ACT, bool LNK, bool RESK, int GRP>
 __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
+    static_assert(!(LNK && RESK), "the folded LayerNorm feeds q|k|v / fc1: no residual");
     constexpr int QT = 16 * 1024;
     constexpr int NSTORE = 16;
-    constexpr int NAUX = LNK ? 5 : 4;                       // ordinary loads per lane per tile in the middle of the epilogue (next tile's bias / LN fragments)
+    // entries of the vector-memory queue a tile's epilogue puts BEHIND the A quarters of the next tile's K-tile 1: the next tile's start values
+    // (bias / LN fragments: 4 / 5 ordinary loads) and, with a residual, the residual rows of passes 1-3 (12 loads); + the 16 stores
+    constexpr int NAUX = (LNK ? 5 : 4) + (RESK ? 12 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3;                                // wave row == GRP
@@ -953,18 +956,36 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
         // ---- tile boundary ------------------------------------------------------------------------------------------------------------------------
         cnt += nk;
         const bool interior = PP_NO_EDGE || m0 + TM <= Mrt;
-        if (has_next) {                                     // the A quarters of the next tile's K-tile 1 -> the stage of the K-tile just finished, BEFORE the stores
-            issue_at(0, 1, (cnt + 1) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
-            issue_at(1, 1, (cnt + 1) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
-        }
+        auto issue_next_a1 = [&]() {                        // the A quarters of the next tile's K-tile 1 -> the stage of the K-tile just finished, BEFORE the stores
+            if (has_next) {
+                issue_at(0, 1, (cnt + 1) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
+                issue_at(1, 1, (cnt + 1) & 1, a_nxt, w_nxt, edge_nxt, lim_nxt);
+            }
+        };
+        if constexpr (!RESK) issue_next_a1();
         {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int slot = lane_e & 7, lrow = lane_e >> 3;
             char* stg = smem + 2 * STAGE + wave * 4096;
-            char* c_wave = reinterpret_cast<char*>(g.C + (int64_t)(m0 + GRP * 128) * g.ldc + (n0 + wn * 64));
+            const int64_t wave_elem = (int64_t)(m0 + GRP * 128) * g.ldc + (n0 + wn * 64);
+            char* c_wave = reinterpret_cast<char*>(g.C + wave_elem);
+            const char* r_wave = reinterpret_cast<const char*>(g.res + (RESK ? wave_elem : 0));
             const unsigned lane_off = (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
             const unsigned row8 = (unsigned)g.ldc * 16u;
+            // With a residual: the rows of pass h + 1 are requested inside pass h (ordinary loads: between the epilogue's own loads and stores no
+            // LDS-DMA request is issued, so the compiler's counted waits see the queue as it is); pass 0's rows are requested here, FIRST, and the
+            // next tile's A quarters go out only after pass 0 has them — requested the other way round, the wait for the rows would also wait for
+            // quarters that were asked for a moment ago.
+            bf16x8 rv[4];
+            auto load_residual = [&](int h) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int grow = m0 + GRP * 128 + h * 32 + it * 8 + lrow;
+                    if (interior || grow < Mrt) rv[it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
+                }
+            };
+            if constexpr (RESK) load_residual(0);
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 float er_pass[2] = {1.f, 1.f};
@@ -997,7 +1018,15 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                     const int row = it * 8 + lrow;
                     ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
                 }
-                if (h == 2 && has_next) load_start(nn0, nm0);   // the next tile's start values: into registers the first two passes freed; NAUX queue entries
+                if constexpr (RESK) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[it][e]);     // round, THEN add the residual (torch's bf16 semantics)
+                    if (h == 0) { asm volatile("" ::: "memory"); issue_next_a1(); }
+                    if (h + 1 < 4) load_residual(h + 1);
+                }
+                if (h == 2 && has_next) load_start(nn0, nm0);   // the next tile's start values: into registers the first two passes freed
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int grow = m0 + GRP * 128 + h * 32 + it * 8 + lrow;
@@ -1017,11 +1046,11 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     if (GRP == 0) bar();                                    // matches the second row's last barrier
 }
 
-template <int ACT, bool LNK>
+template <int ACT, bool LNK, bool RESK = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(PArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave < 4) gemm_pp_body<ACT, LNK, 0>(g, smem); else gemm_pp_body<ACT, LNK, 1>(g, smem);
+    if (wave < 4) gemm_pp_body<ACT, LNK, RESK, 0>(g, smem); else gemm_pp_body<ACT, LNK, RESK, 1>(g, smem);
 }
 
 static bool pp_enabled() {
@@ -1045,12 +1074,14 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
     const dim3 gr(grid), bl(512);
-    if (!res && !g.Cf && g.N % 256 == 0 && g.K >= 128 && !g.tim && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev))) {   // the ping-pong schedule (no residual, whole tiles)
+    static const bool pp_res = [] { const char* e = getenv("SETOK_GEMM_PP_RES"); return !(e && e[0] == '0'); }();     // A/B: residual launches on the old kernel
+    if ((!res || pp_res) && !g.Cf && g.N % 256 == 0 && g.K >= 128 && !g.tim && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev))) {   // the ping-pong schedule (whole tiles)
         static SetokDeviceOnce once_pp;
         if (!once_pp.run([] {
                 bool ok = true;
                 const void* fns[] = {(const void*)gemm_pp_kernel<0, false>, (const void*)gemm_pp_kernel<1, false>, (const void*)gemm_pp_kernel<2, false>,
-                                     (const void*)gemm_pp_kernel<0, true>, (const void*)gemm_pp_kernel<1, true>, (const void*)gemm_pp_kernel<2, true>};
+                                     (const void*)gemm_pp_kernel<0, true>, (const void*)gemm_pp_kernel<1, true>, (const void*)gemm_pp_kernel<2, true>,
+                                     (const void*)gemm_pp_kernel<0, false, true>, (const void*)gemm_pp_kernel<1, false, true>, (const void*)gemm_pp_kernel<2, false, true>};
                 for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
                 return ok; }))
             return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
@@ -1058,6 +1089,10 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
             if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
             else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
             else setok_launch(gemm_pp_kernel<2, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        } else if (res) {
+            if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
+            else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
+            else setok_launch(gemm_pp_kernel<2, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
         } else if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
         else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
         else setok_launch(gemm_pp_kernel<2, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
@@ -1118,7 +1153,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 #endif
         return v;
     }();
-    if (p == 0 && M % TM != 0 && tilesM > 1 && !m_dev && !res && N % 256 == 0 && pp_enabled()) p = 1;   // the ping-pong kernel takes whole 256-row tiles only: the ragged last one goes to the small-tile kernel
+    if (p == 0 && M % TM != 0 && tilesM > 1 && !m_dev && N % 256 == 0 && pp_enabled()) p = 1;   // the ping-pong kernel takes whole 256-row tiles only: the ragged last one goes to the small-tile kernel
     if (dbg & 4 || m_dev) p = 0;                                    // a device-side row count: no host-side split of M
     if (dbg & 8) p = tilesM;                                        // experiment: everything through the deep-pipeline 64x64 kernel
     const int tm_main = tilesM - p;
