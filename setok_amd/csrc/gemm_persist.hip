@@ -868,7 +868,11 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                                                             // exactly NSTORE + NAUX other entries of the vector-memory queue; 2: ahead of an unknown number
     for (;;) {
         // ---- accumulator start --------------------------------------------------------------------------------------------------------------------
+#ifdef PP_ABL_NOINIT
+        if constexpr (false) {
+#else
         if constexpr (LNK) {
+#endif
             auto from_group = [&](float v, int grp) {
                 return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l15 + 16 * grp) << 2, __builtin_bit_cast(int, v)));
             };
@@ -1000,7 +1004,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                     for (int j = 0; j < 4; ++j) {
                         bf16x4 v;
                         f32x4 xs = acc[2 * h + tt][j];
+#ifndef PP_ABL_NOSCALE
                         if constexpr (LNK) xs = xs * er_pass[tt];
+#endif
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = xs[e];

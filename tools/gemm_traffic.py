@@ -44,14 +44,31 @@ def need(d, sub, what):
     return got
 
 
+GEMM_KERNELS = ("gemm_pp_kernel", "gemm_persist_kernel", "gemm_tail_kernel")   # csrc/gemm_persist.hip: ping-pong main kernel, its predecessor
+                                                                                # (ragged / device-side row counts / edge tiles), small-tile tail
+
+
+def _flag(x):
+    return x in ("true", "1")
+
+
 def gemm_class(name):
-    m = re.search(r"gemm_persist_kernel<\s*(\d+)\s*,\s*(\w+)\s*(?:,\s*(\w+)\s*)?(?:,\s*(\w+)\s*)?>", name)
+    """(kernel family, epilogue class) of one instantiation.  Template orders: gemm_pp_kernel<ACT, LNK, RESK>,
+    gemm_persist_kernel<ACT, F32B, RESK, LNK>, gemm_tail_kernel<ACT, LNK, TTM, TTN, NS>."""
+    m = re.search(r"(gemm_pp_kernel|gemm_persist_kernel|gemm_tail_kernel)<([^>]*)>", name)
     if not m:
-        return name
-    act, f32b, resk, lnk = m.group(1), m.group(2), m.group(3) or "false", m.group(4) or "false"
-    if f32b in ("true", "1"):
-        return "fp32_batched"
-    return ACT.get(act, act) + ("+residual" if resk in ("true", "1") else "") + ("+layernorm" if lnk in ("true", "1") else "")
+        return "other", name
+    fam, a = m.group(1), [x.strip() for x in m.group(2).split(",")]
+    a += ["false"] * (4 - len(a))
+    if fam == "gemm_pp_kernel":
+        act, lnk, resk = a[0], _flag(a[1]), _flag(a[2])
+    elif fam == "gemm_persist_kernel":
+        if _flag(a[1]):
+            return fam, "fp32_batched"
+        act, resk, lnk = a[0], _flag(a[2]), _flag(a[3])
+    else:
+        act, lnk, resk = a[0], _flag(a[1]), False
+    return fam, ACT.get(act, act) + ("+residual" if resk else "") + ("+layernorm" if lnk else "")
 
 
 def main():
@@ -72,18 +89,36 @@ def main():
         sys.exit(f"gemm_traffic.py: implausible FETCH_SIZE factor {cal[2] / cal[1]:.3f} from {cal[0]}")
 
     # ---- GEMM, per instantiation --------------------------------------------------------------------------------------------------------
-    gf, gw = need(fetch, "gemm_persist_kernel", "FETCH_SIZE"), need(write, "gemm_persist_kernel", "WRITE_SIZE")
-    per_class, tot_f, tot_w, tot_n = {}, 0.0, 0.0, 0
+    gf, gw = {}, {}
+    for fam in GEMM_KERNELS:
+        gf.update(pick(fetch, fam + "<")); gw.update(pick(write, fam + "<"))
+    if not pick(gf, "gemm_pp_kernel") and not pick(gf, "gemm_persist_kernel"):
+        sys.exit(f"gemm_traffic.py: neither gemm_pp_kernel nor gemm_persist_kernel in the FETCH_SIZE pass; kernels seen: {sorted(fetch)[:40]}")
+    per_class, per_kernel_out, tot_f, tot_w, tot_n = {}, {}, 0.0, 0.0, 0
+    acc = {}
     for name in sorted(gf):
         if name not in gw:
             sys.exit(f"gemm_traffic.py: {name} is in the FETCH_SIZE pass but not in the WRITE_SIZE pass")
         f, w = gf[name], gw[name]
         if len(f) != len(w):
             sys.exit(f"gemm_traffic.py: {name}: {len(f)} launches in the FETCH_SIZE pass, {len(w)} in the WRITE_SIZE pass (not the same command?)")
+        fam, cls = gemm_class(name)
         rf, rw = sum(f) / len(f) * KIB, sum(w) / len(w) * KIB
-        per_class[gemm_class(name)] = {"launches": len(f), "fetch_size_raw_bytes": int(rf), "write_size_raw_bytes": int(rw),
-                                       "traffic_bytes_per_launch": int(rf * corr + rw)}
-        tot_f += sum(f) * KIB; tot_w += sum(w) * KIB; tot_n += len(f)
+        per_kernel_out[f"{fam}:{cls}"] = {"launches": len(f), "fetch_size_raw_bytes": int(rf), "write_size_raw_bytes": int(rw),
+                                          "traffic_bytes_per_launch": int(rf * corr + rw)}
+        if fam != "gemm_tail_kernel":                    # the tail kernel covers the M / N remainders of a launch of the same class: its bytes are added
+            a = acc.setdefault(cls, [0, 0.0, 0.0]); a[0] += len(f)      # to that class, its launches are not
+        else:
+            a = acc.setdefault(cls, [0, 0.0, 0.0])
+        a[1] += sum(f) * KIB; a[2] += sum(w) * KIB
+        tot_f += sum(f) * KIB; tot_w += sum(w) * KIB
+        tot_n += len(f) if fam != "gemm_tail_kernel" else 0
+    for cls, (n, sf, sw) in sorted(acc.items()):
+        if n == 0:                                       # a class only the small-tile kernel runs (latency shapes): count its own launches
+            n = sum(v["launches"] for k, v in per_kernel_out.items() if k == f"gemm_tail_kernel:{cls}")
+            tot_n += n
+        per_class[cls] = {"launches": n, "fetch_size_raw_bytes": int(sf / n), "write_size_raw_bytes": int(sw / n),
+                          "traffic_bytes_per_launch": int((sf * corr + sw) / n)}
 
     # ---- clustering: all kernels of one setok_cluster_dpc_knn call ------------------------------------------------------------------------
     cl, calls = {}, None
@@ -103,8 +138,9 @@ def main():
         "fetch_correction": corr,
         "calibration": f"{cal[0]}, same run: FETCH_SIZE {cal[1] / 1e6:.1f} MB vs WRITE_SIZE {cal[2] / 1e6:.1f} MB for a stream that reads and writes the "
                        f"same number of bytes (16 B per lane) -> x{corr:g}",
-        "gemm": {"kernel": "gemm_persist_kernel<*>", "launches": tot_n, "traffic_bytes_per_launch": int((tot_f * corr + tot_w) / tot_n),
-                 "per_class": per_class},
+        "gemm": {"kernel": "gemm_pp_kernel<*> + gemm_persist_kernel<*> (+ gemm_tail_kernel<*> remainders, attributed to the launch they complete)",
+                 "launches": tot_n, "traffic_bytes_per_launch": int((tot_f * corr + tot_w) / tot_n),
+                 "per_class": per_class, "per_kernel": per_kernel_out},
         "clustering": {"kernels": cl, "calls": calls, "traffic_bytes_per_launch": int(cl_total),
                        "note": "bytes of ALL kernels of one setok_cluster_dpc_knn call (256 images)"},
     }, indent=1))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on the GPU box: bash tools/profile_all.sh r01   (≈10 GPU-minutes)
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
@@ -22,5 +22,8 @@ python tools/bench_gemm.py > $out/gemm_microbench.log 2>&1
 python tools/bench_attn.py 64 >> $out/gemm_microbench.log 2>&1
 python tools/bench_attn.py 48 >> $out/gemm_microbench.log 2>&1
 python tools/bench_attn_causal.py >> $out/gemm_microbench.log 2>&1
+python tools/bench_cluster.py > $out/cluster_microbench.log 2>&1
+python tools/latency.py > $out/latency.log 2>&1
+python tools/bench_vendor_gemm.py > $out/vendor_gemm.log 2>&1
 tail -1 $out/bench_final.json | cut -c1-200
 for w in cfg3 cfg4-forward cfg4 cfg5; do tail -1 $out/bench_$w.json | cut -c1-160; done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace summary of the bench + the two PMC passes for HBM traffic.
 # usage (through gpurun): bash tools/profile_round.sh r02
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Wave-state split of the bench's kernels (SQ counters, one PMC pass each, kernel-trace only): bash tools/profile_wave_states.sh r02
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -11,4 +11,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   db=$(find /tmp/pw_$i -name "*.db" | head -1)
   if [ -n "$db" ]; then python $GRAFT_REPO_ROOT/tools/rocpd_pmc.py $db > $out/bench_pmc_wave_states_$i.txt; else tail -3 $out/pmc_wave_states_$i.log; fi
 done
-cat $out/bench_pmc_wave_states_*.txt | grep -A11 "gemm_persist_kernel<1, false, false, true>\|gemm_persist_kernel<0, false, true, false>\|attn_vit_kernel" | head -120
+cat $out/bench_pmc_wave_states_*.txt | grep -A11 "gemm_pp_kernel<1, true, false>\|gemm_pp_kernel<0, false, true>\|attn_vit_kernel" | head -120
