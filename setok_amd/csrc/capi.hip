@@ -39,7 +39,8 @@ extern "C" int setok_device_info(char* name_host, int name_cap, int* cu_count_ho
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { int kind, cls; double work, bytes; hipEvent_t e0, e1; bool attach, started, stopped; };
+struct ProfRec { int kind, cls; double work, bytes; hipEvent_t e0, e1; bool attach, started, stopped;
+                 int32_t* rows_host; int rows_full; double bytes_fixed; };   // a launch with a DEVICE-side row count: the count is copied back beside the launch
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 volatile int g_prof_on = 0;
@@ -49,7 +50,7 @@ thread_local std::vector<int> g_open;               // indices of this thread's 
 bool setok_prof_on() { return g_prof_on != 0; }
 
 int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes, bool attach) {
-    ProfRec r{kind, cls, work, bytes, nullptr, nullptr, attach, false, false};
+    ProfRec r{kind, cls, work, bytes, nullptr, nullptr, attach, false, false, nullptr, 0, 0.0};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
     if (!attach) { (void)hipEventRecord(r.e0, s); r.started = true; }
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -86,9 +87,23 @@ void setok_prof_end(hipStream_t s, int index) {
     if (!r.stopped) { (void)hipEventRecord(r.e1, s); r.stopped = true; }
 }
 
+// The record's work / bytes were computed for `rows_full` rows; the launch processes *rows_dev (<= rows_full) of them.  The count is copied to a
+// pinned word in stream order (it is final when the launch is enqueued), and setok_profile_stop scales work and the row-proportional bytes
+// (everything but `bytes_fixed`, the weight) by it: a launch sized for the worst case is never credited with rows it skipped.
+void setok_prof_rows(hipStream_t s, int index, const int32_t* rows_dev, int rows_full, double bytes_fixed) {
+    if (index < 0 || !rows_dev || rows_full <= 0) return;
+    int32_t* h = nullptr;
+    if (hipHostMalloc((void**)&h, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return;
+    *h = rows_full;
+    (void)hipMemcpyAsync(h, rows_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (index >= (int)g_prof.size()) { (void)hipHostFree(h); return; }
+    g_prof[index].rows_host = h; g_prof[index].rows_full = rows_full; g_prof[index].bytes_fixed = bytes_fixed;
+}
+
 extern "C" int setok_profile_start(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); if (r.rows_host) (void)hipHostFree(r.rows_host); }
     g_prof.clear();
     g_prof_on = 1;
     return SETOK_OK;
@@ -103,8 +118,14 @@ extern "C" int setok_profile_stop(int* kind, int* cls, double* work, double* byt
         float t = 0.f;
         if (r.kind < 0) ++dropped;
         const bool ok = hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess;
+        if (ok && r.rows_host) {                             // (e1 has completed, hence so has the copy enqueued before the launch)
+            const double f = (double)(*r.rows_host < r.rows_full ? (*r.rows_host < 0 ? 0 : *r.rows_host) : r.rows_full) / (double)r.rows_full;
+            r.work *= f;
+            r.bytes = r.bytes_fixed + (r.bytes - r.bytes_fixed) * f;
+        }
         if (ok && r.kind >= 0 && n < cap && kind && cls && work && bytes && ms) { kind[n] = r.kind; cls[n] = r.cls; work[n] = r.work; bytes[n] = r.bytes; ms[n] = t; ++n; }
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+        if (r.rows_host) (void)hipHostFree(r.rows_host);
     }
     const int total = (int)g_prof.size() - dropped;
     g_prof.clear();

@@ -264,6 +264,7 @@ int setok_linear_dev(void* stream, int dtype, int out_dtype, const void* A, int6
     SetokProfScope prof(s, dtype == SETOK_BF16 ? SETOK_PROF_GEMM_BF16 : SETOK_PROF_GEMM_F32, act | (residual ? 4 : 0), 2.0 * M * N * K * batch,
                         batch * (((double)M * K + (double)N * K) * es_in + (double)M * N * es_out * (residual ? 2 : 1)),   // A, W (+ residual) read once, C written once
                         lds_dma_path);
+    if (m_dev && prof.idx >= 0) setok_prof_rows(s, prof.idx, m_dev, M, batch * (double)N * K * es_in);
     if (dtype == SETOK_BF16) {
         SETOK_CHECK_ARG(K % BK == 0, "setok_linear(bf16): K=%d must be a multiple of %d", K, BK);
         SETOK_CHECK_ARG(lda % 8 == 0, "setok_linear(bf16): lda must be a multiple of 8");

@@ -717,6 +717,11 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 // Linears); the residual launches stay on gemm_persist_kernel (no gain at K = 4096, and no registers for the residual rows beside 96 fragment
 // registers).  SETOK_GEMM_PP=0 switches it off (A/B runs).
 // --------------------------------------------------------------------------------------------
+#ifdef PP_TIMING             // -DPP_TIMING + SETOK_GEMM_TIMING=1: wave 0's cycles per tile in the K loop / the epilogue ("vmcnt waits" column: the accumulator start)
+#define PP_TIMING_ON 1
+#else
+#define PP_TIMING_ON 0
+#endif
 #ifndef PP_NO_EDGE
 #define PP_NO_EDGE 1        // 1: the host hands this kernel whole 256-row tiles only (the remainder rows go to the small-tile kernel, a device-side M to gemm_persist_kernel)
 #endif
@@ -727,7 +732,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     constexpr int NSTORE = 16;
     // entries of the vector-memory queue a tile's epilogue puts BEHIND the A quarters of the next tile's K-tile 1: the next tile's start values
     // (bias / LN fragments: 4 / 5 ordinary loads) and, with a residual, the residual rows of passes 1-3 (12 loads); + the 16 stores
-    constexpr int NAUX = (LNK ? 5 : 4) + (RESK ? 12 : 0);
+    constexpr int NAUX = (LNK ? 14 : 4) + (RESK ? 12 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3;                                // wave row == GRP
@@ -839,18 +844,25 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     auto bar = [&]() { asm volatile("s_barrier" ::: "memory"); };
 
     // what the accumulators of a tile start from: the bias (4 consecutive columns per accumulator register quad), or the folded LayerNorm's
-    // fragments (fetched exactly as gemm_persist_kernel fetches them: one column fragment, the compact form of two row fragments, two rstd)
+    // operand fragments — the same bits gemm_persist_kernel feeds its start MFMAs, fetched lane by lane instead of three loads + 40 ds_bpermute
+    // (measured: no difference in time; kept because it is the shorter code and needs no cross-lane traffic at the tile start)
     f32x4 nbv[4];
-    f32x4 ncw; float2 nrw[2]; float nrs[2], ers[2];
+    float nrs[2], ers[2];
+    f32x4 ncd[4]; float2 nrd[8];                            // the operand fragments of the start MFMAs as the lanes hold them (k-slots 0-7 live in lanes 0-15)
     auto load_start = [&](int n0_, int m0_) {
         if constexpr (LNK) {
-            ncw = *reinterpret_cast<const f32x4*>(g.ln_colsum + 4 * (int64_t)(n0_ + wn * 64 + g4 * 16 + l15));
+            // Every lane fetches its own operand registers: lanes 0-15 the fragments, the others zeros (one 256-byte line of zeros for all of
+            // them) — 12 loads instead of 3, and the tile start has no cross-lane traffic (40 ds_bpermute + 48 selects per wave before).
+            const bool own = g4 == 0;
+            const float* zr = g.zero_bias;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float* st = g.ln_stats + 8 * (int64_t)(PP_NO_EDGE ? m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15 : min(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15, Mrt - 1));
-                nrw[i] = *reinterpret_cast<const float2*>(st);
-                nrs[i] = st[4];
-            }
+            for (int j = 0; j < 4; ++j)
+                ncd[j] = *reinterpret_cast<const f32x4*>(own ? g.ln_colsum + 4 * (int64_t)(n0_ + wn * 64 + j * 16 + l15) : zr + 4 * l15);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                nrd[t] = *reinterpret_cast<const float2*>(own ? g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + t * 16 + l15) : zr + 2 * l15);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) nrs[i] = g.ln_stats[8 * (int64_t)(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15) + 4];
         } else {
             const float* bp = (g.bias ? g.bias + n0_ : g.zero_bias) + (g.bias ? wn * 64 : 0) + 4 * g4;
 #pragma unroll
@@ -866,35 +878,29 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     if (GRP == 1) bar();                                    // the second wave row runs one slot behind
     int ahead = 0;                                          // 1: the A quarters of this tile's K-tile 1 went out in the previous tile's epilogue, ahead of
                                                             // exactly NSTORE + NAUX other entries of the vector-memory queue; 2: ahead of an unknown number
+#ifdef PP_TIMING
+    unsigned long long t_init = 0, t_k = 0, t_epi = 0;
+#endif
     for (;;) {
+#ifdef PP_TIMING
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- accumulator start --------------------------------------------------------------------------------------------------------------------
 #ifdef PP_ABL_NOINIT
         if constexpr (false) {
 #else
         if constexpr (LNK) {
 #endif
-            auto from_group = [&](float v, int grp) {
-                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l15 + 16 * grp) << 2, __builtin_bit_cast(int, v)));
-            };
-            bf16x8 cfr[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = from_group(ncw[e], j);
-                cfr[j] = ln_frag_lane(v, g4);
-            }
             ers[0] = nrs[0]; ers[1] = nrs[1];
             f32x4 z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const float d0 = from_group(nrw[t & 1].x, t >> 1), d1 = from_group(nrw[t & 1].y, t >> 1);
-                const f32x4 v = {d0, d0, d1, d1};
-                const bf16x8 rfr = ln_frag_lane(v, g4);
+                const f32x4 v = {nrd[t].x, nrd[t].x, nrd[t].y, nrd[t].y};            // (-mean hi, lo) twice, (1 / rstd hi, lo) twice
+                const bf16x8 rfr = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ncd[j]), rfr, z, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -902,6 +908,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t][j] = nbv[j];          // bias first, then the products in ascending k: gemm_persist_kernel's order
         }
+#ifdef PP_TIMING
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             const char* T = smem + ((cnt + kt) & 1) * STAGE;
             const bool skipA = ahead != 0 && kt == 0;        // (uniform)
@@ -958,6 +967,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             bar();
         }
         // ---- tile boundary ------------------------------------------------------------------------------------------------------------------------
+#ifdef PP_TIMING
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
         cnt += nk;
         const bool interior = PP_NO_EDGE || m0 + TM <= Mrt;
         auto issue_next_a1 = [&]() {                        // the A quarters of the next tile's K-tile 1 -> the stage of the K-tile just finished, BEFORE the stores
@@ -1030,9 +1042,15 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[it][e]);     // round, THEN add the residual (torch's bf16 semantics)
                     if (h == 0) { asm volatile("" ::: "memory"); issue_next_a1(); }
-                    if (h + 1 < 4) load_residual(h + 1);
+                    if (h + 1 < 4) load_residual(h + 1);          // (all four passes' rows at the top of the epilogue instead: no difference in time; requested
+                                                                  //  inside the tile's last K-tile, the rows need 64 registers the K loop does not have: -14 %)
                 }
-                if (h == 2 && has_next) load_start(nn0, nm0);   // the next tile's start values: into registers the first two passes freed
+#ifndef PP_START_PASS
+#define PP_START_PASS 0     // (A/B: requested in pass 2 instead, the loads are not back when the next tile starts: fc1 with the LayerNorm folded in -3 %)
+#endif
+                // the next tile's start values, into registers the K loop's fragments freed.  Unconditional (after the last tile nn0 / nm0 still name
+                // a tile of this workgroup): a conditional load would make the values loop-carried and keep their registers live across the K loop.
+                if (h == PP_START_PASS) load_start(nn0, nm0);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int grow = m0 + GRP * 128 + h * 32 + it * 8 + lrow;
@@ -1042,6 +1060,10 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the staging rows are rewritten by the next pass)
             }
         }
+#ifdef PP_TIMING
+        { const unsigned long long ts3 = __builtin_amdgcn_s_memtime(); t_init += ts1 - ts0; t_k += ts2 - ts1; t_epi += ts3 - ts2; }
+        if (!has_next && g.tim && tid == 0) { g.tim[blockIdx.x * 4 + 0] = t_k; g.tim[blockIdx.x * 4 + 1] = t_epi; g.tim[blockIdx.x * 4 + 2] = t_init; g.tim[blockIdx.x * 4 + 3] = (unsigned long long)(round + 1) << 40; }
+#endif
         if (!has_next) break;
         ahead = interior ? 1 : 2;
         m0 = nm0; n0 = nn0; ++round;
@@ -1081,7 +1103,7 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
     const bool res = g.res && !(g.dbg & 2);
     const dim3 gr(grid), bl(512);
     static const bool pp_res = [] { const char* e = getenv("SETOK_GEMM_PP_RES"); return !(e && e[0] == '0'); }();     // A/B: residual launches on the old kernel
-    if ((!res || pp_res) && !g.Cf && g.N % 256 == 0 && g.K >= 128 && !g.tim && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev))) {   // the ping-pong schedule (whole tiles)
+    if ((!res || pp_res) && !g.Cf && g.N % 256 == 0 && g.K >= 128 && (PP_TIMING_ON || !g.tim) && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev))) {   // the ping-pong schedule (whole tiles)
         static SetokDeviceOnce once_pp;
         if (!once_pp.run([] {
                 bool ok = true;
@@ -1168,7 +1190,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
     PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1,
             ln_stats, ln_colsum, m_dev};
-    if (!bias) {
+    if (!bias || ln_stats) {
         const float* zb = zero_bias();
         if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot resolve the zero-bias symbol");
         g.zero_bias = zb;
