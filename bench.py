@@ -426,7 +426,7 @@ def main():
                                     if trainer is not None else f"dp{world} (images sharded, no data-path collective)") + ("" if args.backend == "nccl" and not args.share_gpu else
                                                                                                    f" [VALIDATION RUN: backend {args.backend}, ranks share one GPU: not a scaling number]"),
                        "per_rank": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"]},
-            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<*> (bf16 MFMA GEMM of every large Linear)" if args.dtype == "bf16"
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<*> / gemm_persist_kernel<*> / gemm_tail_kernel<*> (every bf16 MFMA GEMM launch of the step)" if args.dtype == "bf16"
                          else "gemm_f32_kernel (exact-f32 MFMA GEMM, parity mode)",
                          "achieved": round(achieved, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
