@@ -848,7 +848,14 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     // (measured: no difference in time; kept because it is the shorter code and needs no cross-lane traffic at the tile start)
     f32x4 nbv[4];
     float nrs[2], ers[2];
-    f32x4 ncd[4]; float2 nrd[8];                            // the operand fragments of the start MFMAs as the lanes hold them (k-slots 0-7 live in lanes 0-15)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 ncd[4]; f32x2 nrd[8];                             // the operand fragments of the start MFMAs as the lanes hold them (k-slots 0-7 live in lanes 0-15)
+    // The loads are inline assembly and the wait for them is explicit (start_ready): as ordinary loads the compiler waited for them at the loop
+    // header with the counts of the kernel-entry path (`vmcnt(0)` for the last one) — on the loop's back edge that is a full drain of the
+    // previous tile's sixteen stores, ~2.5 k ticks per tile.  
+    auto ld16 = [&](f32x4& dst, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); };
+    auto ld8 = [&](f32x2& dst, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); };
+    auto ld4 = [&](float& dst, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); };
     auto load_start = [&](int n0_, int m0_) {
         if constexpr (LNK) {
             // Every lane fetches its own operand registers: lanes 0-15 the fragments, the others zeros (one 256-byte line of zeros for all of
@@ -856,18 +863,27 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             const bool own = g4 == 0;
             const float* zr = g.zero_bias;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ncd[j] = *reinterpret_cast<const f32x4*>(own ? g.ln_colsum + 4 * (int64_t)(n0_ + wn * 64 + j * 16 + l15) : zr + 4 * l15);
+            for (int j = 0; j < 4; ++j) ld16(ncd[j], own ? g.ln_colsum + 4 * (int64_t)(n0_ + wn * 64 + j * 16 + l15) : zr + 4 * l15);
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                nrd[t] = *reinterpret_cast<const float2*>(own ? g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + t * 16 + l15) : zr + 2 * l15);
+            for (int t = 0; t < 8; ++t) ld8(nrd[t], own ? g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + t * 16 + l15) : zr + 2 * l15);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) nrs[i] = g.ln_stats[8 * (int64_t)(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15) + 4];
+            for (int i = 0; i < 2; ++i) ld4(nrs[i], g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15) + 4);
         } else {
             const float* bp = (g.bias ? g.bias + n0_ : g.zero_bias) + (g.bias ? wn * 64 : 0) + 4 * g4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) nbv[j] = *reinterpret_cast<const f32x4*>(bp + (g.bias ? j * 16 : 0));
+            for (int j = 0; j < 4; ++j) ld16(nbv[j], bp + (g.bias ? j * 16 : 0));
         }
+    };
+    // ... and the wait: behind the start values of a tile the queue holds the previous tile's 16 stores (+ with a residual the rows of passes 2 and 3,
+    // 8 loads); at the kernel's entry the stream start has already waited for them.  The values pass through
+    // the statement, so nothing that reads them can be scheduled above it.
+    constexpr int NBEHIND = NSTORE + (RESK ? 8 : 0);
+    auto start_ready = [&]() {
+        if constexpr (LNK)
+            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(ncd[0]), "+v"(ncd[1]), "+v"(ncd[2]), "+v"(ncd[3]), "+v"(nrd[0]), "+v"(nrd[1]), "+v"(nrd[2]), "+v"(nrd[3]),
+                         "+v"(nrd[4]), "+v"(nrd[5]), "+v"(nrd[6]), "+v"(nrd[7]), "+v"(nrs[0]), "+v"(nrs[1]) : [n] "n"(NBEHIND) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(nbv[0]), "+v"(nbv[1]), "+v"(nbv[2]), "+v"(nbv[3]) : [n] "n"(NBEHIND) : "memory");
     };
 
     // ---- start of the stream: the first tile's start values, K-tile 0 entirely + the W quarters of K-tile 1 --------------------------------------
@@ -886,18 +902,20 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- accumulator start --------------------------------------------------------------------------------------------------------------------
+        start_ready();
 #ifdef PP_ABL_NOINIT
         if constexpr (false) {
 #else
         if constexpr (LNK) {
 #endif
             ers[0] = nrs[0]; ers[1] = nrs[1];
+            asm volatile("" : "+v"(ers[0]), "+v"(ers[1]));   // values of THIS point: without it the epilogue's first use waits `vmcnt(0)` — for the operand DMA in flight
             f32x4 z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const f32x4 v = {nrd[t].x, nrd[t].x, nrd[t].y, nrd[t].y};            // (-mean hi, lo) twice, (1 / rstd hi, lo) twice
+                const f32x4 v = {nrd[t][0], nrd[t][0], nrd[t][1], nrd[t][1]};            // (-mean hi, lo) twice, (1 / rstd hi, lo) twice
                 const bf16x8 rfr = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ncd[j]), rfr, z, 0, 0, 0);
