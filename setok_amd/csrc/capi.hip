@@ -25,7 +25,7 @@ extern "C" int setok_device_info(char* name_host, int name_cap, int* cu_count_ho
         return setok_fail(SETOK_EUNSUPPORTED, "no HIP device visible");
     }
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return setok_fail(SETOK_ELAUNCH, "hipGetDeviceProperties failed");
     if (name_host && name_cap > 0) {
