@@ -20,8 +20,8 @@ def rel(a, b):
 
 
 def fuzz_linear():
-    M = rng.choice([1, 3, 64, 255, 257, 300, 771, 1028, 4100, 9300, 16448, rng.randint(1, 20000)])
-    N = 64 * rng.randint(1, 48)
+    M = rng.choice([1, 3, 64, 255, 257, 300, 771, 1028, 4100, 9300, 16448, 256 * rng.randint(8, 72), 256 * rng.randint(8, 72) + rng.randint(1, 255), rng.randint(1, 20000)])
+    N = rng.choice([64 * rng.randint(1, 48), 256 * rng.randint(1, 16)])      # multiples of 256 with >= 48 tiles: the ping-pong kernel (whole tiles) + the small-tile remainder
     K = 64 * rng.randint(1, 64)
     act = rng.randint(0, 2)
     use_res = rng.random() < 0.5
@@ -45,8 +45,8 @@ def fuzz_linear():
 
 
 def fuzz_linear_ln():
-    M = rng.choice([5, 257, 771, 4100, 16448, rng.randint(1, 12000)])
-    N = 64 * rng.randint(1, 48)
+    M = rng.choice([5, 257, 771, 4100, 16448, 256 * rng.randint(8, 72), 256 * rng.randint(8, 72) + rng.randint(1, 255), rng.randint(1, 12000)])
+    N = rng.choice([64 * rng.randint(1, 48), 256 * rng.randint(1, 16)])
     K = 64 * rng.randint(1, 32)
     act = rng.randint(0, 2)
     g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
@@ -59,6 +59,10 @@ def fuzz_linear_ln():
     y = y * torch.sigmoid(1.702 * y) if act == 1 else (F.gelu(y) if act == 2 else y)
     e = rel(got, y)
     assert e < 1.5e-2, ("linear_ln", M, N, K, act, e)
+    if M > 600:
+        lo = rng.randint(0, M - 300)
+        sub = ops.linear_ln(x[lo:lo + 257].contiguous(), ops.ln_fold(w, gamma, beta, bias), st[lo:lo + 257].contiguous(), act=act)
+        assert torch.equal(sub, got[lo:lo + 257].to(sub.dtype)), ("linear_ln rows differ between kernels", M, N, K, act, lo)
     return ("linear_ln", M, N, K, act)
 
 
@@ -124,9 +128,9 @@ def fuzz_cross_attention():
 
 
 def fuzz_cluster():
-    N = rng.choice([256, 256, 196, 64, 144, rng.randint(2, 256)])
+    N = rng.choice([256, 256, 196, 64, 144, rng.randint(2, 256), 576, 324, rng.randint(257, 576)])     # > 256: the strip kernel (workgroups of an image exchange rho / scores)
     C = 64 * rng.randint(1, 16)
-    B = rng.randint(1, 9)
+    B = rng.randint(1, 9) if N <= 256 else rng.choice([1, 2, 3, 60, 130])     # (> 51 images: more items than workgroups)
     k = rng.randint(1, min(N, 96))
     mcn = rng.randint(1, min(N, 64))
     thr = rng.choice([0.5, 0.12, 0.13, 1e9, 0.0])
