@@ -1037,12 +1037,25 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #ifndef PP_ABL_NOSCALE
                         if constexpr (LNK) xs = xs * er_pass[tt];
 #endif
+                        if constexpr (ACT == SETOK_ACT_QUICK_GELU) {
+                            // the same five operations per element as everywhere else (bit-identical), written on pairs so that the two multiplies
+                            // and the add issue as packed instructions: 9 instead of 11 VALU instructions per two elements
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = xs[e];
-                            if (ACT == SETOK_ACT_QUICK_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.45546696f * x));
-                            else if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
-                            v[e] = (bf16)x;
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 x2 = {xs[e], xs[e + 1]};
+                                const f32x2 t = x2 * f32x2{-2.45546696f, -2.45546696f};
+                                const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+                                const f32x2 y = x2 * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                                v[e] = (bf16)y[0]; v[e + 1] = (bf16)y[1];
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = xs[e];
+                                if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
+                                v[e] = (bf16)x;
+                            }
                         }
                         const int srow = tt * 16 + l15;
                         *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((j * 2 + (g4 >> 1)) ^ (srow & 7)) << 4) + 8 * (g4 & 1)) = v;
