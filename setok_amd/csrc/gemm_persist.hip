@@ -1032,30 +1032,35 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        // Everything on PAIRS (register-aligned halves of the accumulator quad): the rstd scaling, the activation's multiplies / add
+                        // and the conversion issue as packed instructions.  Left to itself the compiler paired elements 1 and 2 of the quad and
+                        // patched the bf16 words together with v_perm / v_alignbit (10 instructions per quad instead of 4).
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
                         bf16x4 v;
-                        f32x4 xs = acc[2 * h + tt][j];
+                        const f32x4 xq = acc[2 * h + tt][j];
+                        if constexpr (ACT == SETOK_ACT_GELU_ERF) {           // (element by element as in the other kernels: on pairs the compiler contracts
+                            f32x4 xs = xq;                                   //  the polynomial differently and the last bit moves)
 #ifndef PP_ABL_NOSCALE
-                        if constexpr (LNK) xs = xs * er_pass[tt];
+                            if constexpr (LNK) xs = xs * er_pass[tt];
 #endif
-                        if constexpr (ACT == SETOK_ACT_QUICK_GELU) {
-                            // the same five operations per element as everywhere else (bit-identical), written on pairs so that the two multiplies
-                            // and the add issue as packed instructions: 9 instead of 11 VALU instructions per two elements
-                            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                            for (int e = 0; e < 4; e += 2) {
-                                const f32x2 x2 = {xs[e], xs[e + 1]};
+                            for (int e = 0; e < 4; ++e) v[e] = (bf16)gelu_erf_fast(xs[e]);
+                        } else
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x2 x2 = {xq[e], xq[e + 1]};
+#ifndef PP_ABL_NOSCALE
+                            if constexpr (LNK) x2 = x2 * f32x2{er_pass[tt], er_pass[tt]};
+#endif
+                            if constexpr (ACT == SETOK_ACT_QUICK_GELU) {
+                                // x * sigmoid(1.702 x), 1.702 log2(e) = 2.45546696: the same five operations per element as in the other kernels
                                 const f32x2 t = x2 * f32x2{-2.45546696f, -2.45546696f};
                                 const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-                                const f32x2 y = x2 * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                                v[e] = (bf16)y[0]; v[e + 1] = (bf16)y[1];
+                                x2 = x2 * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
                             }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float x = xs[e];
-                                if (ACT == SETOK_ACT_GELU_ERF) x = gelu_erf_fast(x);
-                                v[e] = (bf16)x;
-                            }
+                            const bf16x2 b2 = __builtin_convertvector(x2, bf16x2);
+                            v[e] = b2[0]; v[e + 1] = b2[1];
                         }
                         const int srow = tt * 16 + l15;
                         *reinterpret_cast<bf16x4*>(stg + srow * 128 + (((j * 2 + (g4 >> 1)) ^ (srow & 7)) << 4) + 8 * (g4 & 1)) = v;
