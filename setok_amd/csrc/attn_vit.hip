@@ -15,6 +15,9 @@
 
 namespace {
 
+#ifndef ATTN_O_SWAP
+#define ATTN_O_SWAP 1
+#endif
 constexpr int ROWB = 128;              // bytes per K / V row in LDS: 64 dims; a 48-dim head leaves two 16-byte slots of each row unused
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
@@ -167,7 +170,37 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
-        if (q < Tq) {
+        if constexpr (!CROSS && DH == 64 && ATTN_O_SWAP) {
+            // The lane pair (q, q + 32) holds the query's 64 output dims in alternating 4-dim chunks (chunk j = d * 4 + r4: dims 8 j + 4 hi .. + 3).
+            // One v_permlane32_swap per register exchanges the upper lanes' chunk j with the lower lanes' chunk j + 4: afterwards lane q owns dims
+            // 0-31 and lane q + 32 dims 32-63 in 16-byte pieces — 4 stores of 16 bytes per lane instead of 8 of 8.
+            unsigned cw[8][2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[d][r4 * 4 + j] * inv);
+                    const uint2 u2 = __builtin_bit_cast(uint2, v);
+                    cw[d * 4 + r4][0] = u2.x; cw[d * 4 + r4][1] = u2.y;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(cw[j][w], cw[j + 4][w], false, false);
+                    cw[j][w] = r[0]; cw[j + 4][w] = r[1];
+                }
+            if (q < Tq) {
+                bf16* op = out + ((int64_t)b * Tq + q) * (int64_t)C + h * DH + hi * 32;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint4 piece = {cw[j][0], cw[j][1], cw[j + 4][0], cw[j + 4][1]};
+                    *reinterpret_cast<uint4*>(op + 8 * j) = piece;
+                }
+            }
+        } else if (q < Tq) {
             bf16* op = out + ((int64_t)b * Tq + q) * (CROSS ? ldo : (int64_t)C) + h * DH;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
