@@ -15,6 +15,9 @@
 
 namespace {
 
+#ifndef ATTN_STAGE_SBASE
+#define ATTN_STAGE_SBASE 1
+#endif
 #ifndef ATTN_O_SWAP
 #define ATTN_O_SWAP 1
 #endif
@@ -75,7 +78,30 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const int npieces = Tp * 8;                                  // 16-byte pieces per operand; Tp*8 is a multiple of 64
+        // A request = 8 rows x 8 pieces; (p0 >> 3) is a multiple of 8, so a lane's row inside the request, its piece and K's swizzle are the same for
+        // every request: ONE 32-bit lane offset per operand, the row advance goes into a wave-uniform 64-bit base (scalar adds).  Formed per lane
+        // and per request (64-bit multiplies, clamps) the addresses were 68 vector instructions per pair of requests — a third of what a wave
+        // spends on a whole query tile's key loop.  Only a request that reaches past row T - 1 still clamps per lane.
+        const int r8 = lane >> 3, c8 = lane & 7, kc8 = c8 ^ r8;
+        const unsigned koff = (unsigned)r8 * (unsigned)(ldk * 2) + (unsigned)((kc8 < DH / 8 ? kc8 : 0) << 4);
+        const unsigned voff = (unsigned)r8 * (unsigned)(ldk * 2) + (unsigned)((c8 < DH / 8 ? c8 : 0) << 4);
+        auto dma_s = [&](const char* base, unsigned off, unsigned dst) {
+            unsigned keep;
+            const unsigned long long b64 = (unsigned long long)base;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+            const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(sb64), "s"(dst) : "memory");
+        };
         for (int p0 = wave_u * 64; p0 < npieces; p0 += NW * 64) {    // this wave's 64 consecutive pieces
+            const int key0 = p0 >> 3;
+            if (ATTN_STAGE_SBASE && key0 + 8 <= T) {                  // (uniform) all eight rows exist
+                const size_t rbytes = (size_t)key0 * (size_t)(ldk * 2);
+                dma_s(reinterpret_cast<const char*>(kbase) + rbytes, koff, lds0 + p0 * 16);
+                dma_s(reinterpret_cast<const char*>(vbase) + rbytes, voff, lds0 + Tp * ROWB + p0 * 16);
+                continue;
+            }
             const int p = p0 + lane, key = p >> 3, c = p & 7;
             const int64_t roff = (int64_t)min(key, T - 1) * ldk;
             const int kc = c ^ (key & 7);                               // physical slot c of row `key` holds logical chunk c ^ (key & 7)
