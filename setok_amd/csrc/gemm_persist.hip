@@ -722,6 +722,9 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #else
 #define PP_TIMING_ON 0
 #endif
+#ifndef PP_GM
+#define PP_GM 8            // M-tiles per group of the tile order (cfg2, same box: 4 = 8; 16: -1 %; 32: -4.7 %)
+#endif
 #ifndef PP_NO_EDGE
 #define PP_NO_EDGE 1        // 1: the host hands this kernel whole 256-row tiles only (the remainder rows go to the small-tile kernel, a device-side M to gemm_persist_kernel)
 #endif
@@ -747,7 +750,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
         if ((G & 7) == 0) L = round * G + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
         else L = round * G + blockIdx.x;
         if (L >= num_tiles) return false;
-        constexpr int GM = 8;
+        constexpr int GM = PP_GM;
         const int per = GM * g.tilesN, group = L / per, first_m = group * GM;
         const int gm = min(tilesMrt - first_m, GM), in = L - group * per;
         m0 = (first_m + in % gm) * TM;
