@@ -53,7 +53,7 @@ def log(msg):
 
 WORKLOADS = {
     # name: (image size, images per GPU, decoder?, description)
-    "cfg2": (224, 256, False, "cfg2: ViT-L/14 224^2 (23 of 24 layers, select_layer=-2), dyn-k DPC-kNN (k=64, threshold=0.125), SeTok head "
+    "cfg2": (224, 256, False, "cfg2: ViT-L/14 224^2 (24 of 24 layers, select_layer=-1 as the reference's launch scripts pass it), dyn-k DPC-kNN (k=64, threshold=0.125), SeTok head "
                                "1024/2 heads/ff 4096 -> 4096, mm_in_projector mlp2x_gelu; encode-only"),
     "cfg4-forward": (336, 128, False, "cfg4 shapes, FORWARD ONLY (the training step is not built): ViT-L/14 336^2 = 576 patches, dyn-k, batch 128 "
                                        "per GPU, same head and projector as cfg2"),
@@ -78,7 +78,7 @@ def build_decoder(device):
     return det.to(device=device, dtype=torch.bfloat16).eval()
 
 
-def build_model(device, img=IMG, dtype=torch.bfloat16, select_layer=-2):
+def build_model(device, img=IMG, dtype=torch.bfloat16, select_layer=-1):
     import setok_amd
     from setok_amd.synthetic import init_synthetic_
     vit = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
@@ -241,11 +241,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="bf16 = the BASELINE metric's precision; f32 = the parity-exact mode (bit-exact cluster indices, 1e-4 features)")
-    ap.add_argument("--select-layer", type=int, default=-2,
-                    help="hidden_states index the tower returns: -2 = the reference classes' default (tokenizer.py:18, 23 of 24 layers run); "
-                         "-1 = what the reference's launch scripts pass (scripts/pretrain_mm_proj.sh:43, all 24 layers)")
+    ap.add_argument("--select-layer", type=int, default=-1,
+                    help="hidden_states index the tower returns: -1 (default) = what the reference's launch scripts pass and its training dataclass "
+                         "defaults to (scripts/pretrain_mm_proj.sh:43, scripts/finetune.sh:67, src/train/training_utils.py:25: all 24 layers run); "
+                         "-2 = the reference classes' own default (tokenizer.py:18, 23 of 24 layers), reported beside it as `also_select_layer_minus2`")
     ap.add_argument("--timed-only", action="store_true",
-                    help="profiling runs: nothing but warm-up + the timed steps (no clock / power sampling loop, no select_layer = -1 steps, no CPU "
+                    help="profiling runs: nothing but warm-up + the timed steps (no clock / power sampling loop, no select_layer = -2 steps, no CPU "
                          "baseline), so that two rocprofv3 passes of the same command see the same launches")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL over xGMI) is the measured configuration; gloo + --share-gpu run the multi-rank logic on a one-GPU box (validation only)")
@@ -287,8 +288,10 @@ def main():
     import setok_amd
     from setok_amd import ops
     log(f"rank {rank}/{world}: building model")
-    if args.select_layer != -2:
-        workload_desc = workload_desc.replace("23 of 24 layers, select_layer=-2", f"select_layer={args.select_layer}")
+    if args.select_layer != -1:
+        n_run = 24 + 1 + args.select_layer if args.select_layer < 0 else args.select_layer
+        workload_desc = workload_desc.replace("24 of 24 layers, select_layer=-1 as the reference's launch scripts pass it",
+                                              f"{n_run} of 24 layers, select_layer={args.select_layer}")
     if args.dtype == "f32":
         workload_desc += "; fp32 parity mode (exact-f32 MFMA GEMMs)"
     tok, proj = build_model(dev, img, dtype, args.select_layer)
@@ -377,11 +380,11 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
-    # the select_layer = -1 number beside the -2 one (the reference's launch scripts run all 24 layers): a few extra steps, untimed above
+    # the select_layer = -2 number (the reference classes' default, 23 layers) beside the headline's -1: a few extra steps, untimed above
     other = None
-    if rank == 0 and args.workload == "cfg2" and world == 1 and args.select_layer == -2 and not args.timed_only:
+    if rank == 0 and args.workload == "cfg2" and world == 1 and args.select_layer == -1 and not args.timed_only:
         tower = tok.image_feature_encoder
-        tower.select_layer = -1
+        tower.select_layer = -2
         setok_amd.encode_images(tok, proj, images); torch.cuda.synchronize()
         n_o = max(2, min(args.steps, 5))
         t1 = time.perf_counter()
@@ -389,14 +392,14 @@ def main():
             o2 = setok_amd.encode_images(tok, proj, images)
         torch.cuda.synchronize()
         d1 = (time.perf_counter() - t1) / n_o
-        other = {"select_layer": -1, "layers_run": 24, "images_per_s": round(B / d1, 2), "ms_per_step": round(d1 * 1e3, 3), "steps": n_o,
+        other = {"select_layer": -2, "layers_run": 23, "images_per_s": round(B / d1, 2), "ms_per_step": round(d1 * 1e3, 3), "steps": n_o,
                  "tokens_per_image_mean": round(sum(o2.counts) / len(o2.counts), 2)}
-        tower.select_layer = -2
+        tower.select_layer = -1
 
     # clock / power under load: rank 0 re-runs the step while polling rocm-smi — only where the step has no collective (a training step's
     # all-reduce would wait for ranks that are not stepping)
     telemetry = gpu_telemetry(step, local) if rank == 0 and not args.timed_only and (world == 1 or trainer is None) else None
-    traffic, traffic_note = load_traffic(args.workload == "cfg2" and args.dtype == "bf16" and B == 256 and args.select_layer == -2)
+    traffic, traffic_note = load_traffic(args.workload == "cfg2" and args.dtype == "bf16" and B == 256 and args.select_layer == -1)
     if rank == 0:
         gname = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -465,7 +468,7 @@ def main():
                 res["roofline"]["peak_at_measured_clock"] = round(pk, 1)
                 res["roofline"]["frac_at_measured_clock"] = round(achieved / pk, 4)
         if other:
-            res["config"]["also_select_layer_minus1"] = other
+            res["config"]["also_select_layer_minus2"] = other
         if det is not None:
             res["config"]["reconstruction_mse"] = round(float(step.recon_loss), 6)      # the step's terminal scalar (random-init decoder vs a random gold image)
         if llm is not None:
