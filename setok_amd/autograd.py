@@ -12,8 +12,11 @@ inside the transposes for db, setok_gelu_bwd, setok_layernorm_bwd, setok_splice_
     SpliceRowsFn  splice_multimodal (the embedding + image rows)    d loss / d projected image tokens (d embed_tokens.weight on request)
     HeadFn        SetokTokenizer.encode_features                    d loss / d head parameters (inner_encoder, inter_encoder, out)
 
-Everything else on the path is inference-only and says so: `refuse_grad` raises when gradients are enabled and a parameter of the module
-requires one (instead of silently returning a tensor without a graph, which is what round 2 did).  The forward values are the inference
+Everything else on the path is inference-only and says so (round 4): the forward always runs — reference-style inference callers
+do not wrap their calls in no_grad and freshly built modules have trainable parameters — and, when torch would have recorded a graph, the
+outputs carry a grad_fn whose backward RAISES (`no_backward`), so nothing trains silently.  The CLIP tower, whose reference forward is itself
+`@torch.no_grad()`, warns once and proceeds.  `refuse_grad` (raise at the call) is left for inputs a caller explicitly marked as needing a
+gradient that cannot be delivered.  The forward values are the inference
 path's, bit for bit, for the projector and the splice; the head's training forward keeps its pre-activation (training.py)."""
 from __future__ import annotations
 
@@ -36,8 +39,8 @@ def grad_needed(*tensors) -> bool:
 
 
 def refuse_grad(what: str, tensors: Iterable[Any], hint: str = "") -> None:
-    """The loud guard of every inference-only forward: a module whose parameters require a gradient, called with gradients enabled, would
-    silently train nothing."""
+    """The loud guard for an INPUT a caller explicitly asked a gradient for and cannot get (features handed to the head's training step with
+    `requires_grad=True`, ...): raising at the call is the only honest answer there."""
     if not torch.is_grad_enabled():
         return
     for t in tensors:
@@ -46,6 +49,62 @@ def refuse_grad(what: str, tensors: Iterable[Any], hint: str = "") -> None:
                 f"{what} runs on the HIP library without an autograd graph, but gradients are enabled and one of its inputs / parameters "
                 f"requires a gradient: the result would silently train nothing.  Freeze it (`requires_grad_(False)`, what the reference's "
                 f"stage-2 recipe does for everything but mm_in_projector) or call it under `torch.no_grad()`." + (" " + hint if hint else ""))
+
+
+class _NoBackwardFn(torch.autograd.Function):
+    """Identity whose backward raises: the grad_fn of an inference-only module's output when autograd would have expected a graph."""
+
+    @staticmethod
+    def forward(ctx, out, what, *deps):
+        ctx.what = what
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(
+            f"{ctx.what} ran on the HIP library without an autograd graph (it has no backward pass there): backward() through its output "
+            f"would silently train nothing.  Freeze the module (`requires_grad_(False)`), call it under `torch.no_grad()`, or detach its output.")
+
+
+def no_backward(what: str, value, deps: Iterable[Any]):
+    """Inference-only modules whose REFERENCE counterpart is differentiable (Block, SetokDeTokenizer, the LLM prefill): the forward runs as
+    inference whatever the grad mode — a freshly built nn.Module has `requires_grad=True` parameters and reference-style inference callers do
+    not wrap their calls — and, where torch would have recorded a graph (gradients enabled + an input / parameter requiring one),
+    every floating-point tensor of the result carries a grad_fn that RAISES in backward.  Nothing trains silently, nothing that only wants the
+    values crashes."""
+    if not torch.is_grad_enabled():
+        return value
+    live = [t for t in deps if isinstance(t, torch.Tensor) and t.requires_grad]
+    if not live:
+        return value
+
+    def wrap(v):
+        if isinstance(v, torch.Tensor):
+            return _NoBackwardFn.apply(v, what, *live) if v.is_floating_point() else v
+        if isinstance(v, tuple):
+            return tuple(wrap(u) for u in v)
+        if isinstance(v, list):
+            return [wrap(u) for u in v]
+        if isinstance(v, dict):
+            return {k: wrap(u) for k, u in v.items()}
+        return v
+    return wrap(value)
+
+
+_WARNED: set = set()
+
+
+def warn_no_grad_once(what: str, tensors: Iterable[Any], why: str) -> None:
+    """For a module whose REFERENCE forward is itself `@torch.no_grad()` (the CLIP tower, clip_encoder.py:50): parameters that require a
+    gradient get none there either, so the call proceeds exactly like the reference's — with one warning per process saying so."""
+    if not torch.is_grad_enabled() or what in _WARNED:
+        return
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            import warnings
+            _WARNED.add(what)
+            warnings.warn(f"{what}: gradients are enabled and a parameter requires one, but {why}; running without a graph.", UserWarning, stacklevel=3)
+            return
 
 
 def _grad_as(g: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:

@@ -213,11 +213,12 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
 
     def hidden_rows(self, images: torch.Tensor) -> torch.Tensor:
         """(B*(N+1), C) rows of hidden_states[select_layer] (class token first in each image).  Inference only, like the reference's
-        `@torch.no_grad()` forward (clip_encoder.py:50) — but a tower whose parameters were unfrozen (`unfreeze_mm_vision_tower`, or a manual
-        `requires_grad_(True)`) is refused loudly rather than silently not trained."""
+        `@torch.no_grad()` forward (clip_encoder.py:50): a tower whose parameters were unfrozen (`unfreeze_mm_vision_tower`, or a manual
+        `requires_grad_(True)`) gets no gradient in the reference either; here that is said once, as a warning."""
         if not self.is_loaded:
             raise RuntimeError("vision tower not loaded: call load_model() first")
-        autograd.refuse_grad("CLIPVisionTower (the ViT tower has no backward pass on the HIP path)", self.vision_tower.parameters())
+        autograd.warn_no_grad_once("CLIPVisionTower", self.vision_tower.parameters(),
+                                   "the tower's forward is @torch.no_grad() in the reference (clip_encoder.py:50) and has no backward pass on the HIP path")
         with torch.no_grad():
             return self._hidden_rows(images)
 

@@ -73,7 +73,7 @@ class EncodeContext:
             pass
 
     def encode(self, images: torch.Tensor, k: Optional[int] = None, threshold: Optional[float] = None, noise=None, token_mask=None,
-               return_stages: bool = False, sync: bool = True):
+               return_stages: bool = False, sync: bool = True, ws: Optional[torch.Tensor] = None):
         """images (B, 3, H, W) on the context's device -> (packed tokens (sum L_i, D), counts list, idx_cluster (B, N) int64,
         score (B, N) fp32, index_down (B, N) int64[, stages]).
 
@@ -84,7 +84,11 @@ class EncodeContext:
         B, N, dev = images.shape[0], self.N, self.device
         x = images.to(device=dev, dtype=self.dtype).contiguous()
         nbytes = _lib.load().setok_encode_workspace_bytes(self.handle, B)
-        ws = self._ws.get(B)
+        if ws is not None:                                                # a caller-owned workspace (GraphedEncode: the captured launches point into it)
+            if ws.numel() < nbytes or ws.dtype != torch.uint8 or ws.device != dev:
+                raise ValueError(f"workspace must be a uint8 tensor of >= {nbytes} bytes on {dev}")
+        else:
+            ws = self._ws.get(B)
         if ws is None or ws.numel() < nbytes:
             self._ws = {B: torch.empty(nbytes, dtype=torch.uint8, device=dev)}            # one batch size cached: the workspace is the activations' size
             ws = self._ws[B]
@@ -129,19 +133,36 @@ class GraphedEncode:
     captured ONCE per batch size into a HIP graph on static buffers and replayed; per call the host then pays one graph launch, one copy of the
     images into the static input and one read of the B token counts.  Bit-identical to the eager call (the same kernels on the same data)."""
 
-    def __init__(self, ctx: "EncodeContext", B: int, k: Optional[int] = None, threshold: Optional[float] = None):
-        self.ctx, self.B = ctx, B
-        cfg_side = int(round((ctx.N) ** 0.5))
+    def __init__(self, ctx, B: int, k: Optional[int] = None, threshold: Optional[float] = None):
+        """`ctx`: an EncodeContext, or — preferred — the SetokTokenizer itself: the graph then follows the module (a weight update, `.to()`, a
+        changed select_layer rebuild the module's context, and the next call re-captures instead of replaying launches that read the OLD
+        context's weight copies).  Given a bare context the graph is pinned to it and says so when asked (`stale()` is always False)."""
+        self.tok = None
+        if not isinstance(ctx, EncodeContext):
+            self.tok, ctx = ctx, ctx._context()
+        self.B, self.k, self.threshold = B, k, threshold
+        self._capture(ctx)
+
+    def _capture(self, ctx: "EncodeContext"):
+        self.ctx, B = ctx, self.B
         self.images = torch.zeros((B, 3, ctx.image_size, ctx.image_size), dtype=ctx.dtype, device=ctx.device)
-        ctx.encode(self.images, k, threshold, sync=False)                              # warm-up: one-time attribute calls must not land in the capture
+        nbytes = _lib.load().setok_encode_workspace_bytes(ctx.handle, B)
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)          # the graph's OWN workspace: eager encode() calls of the same batch size
+        ctx.encode(self.images, self.k, self.threshold, sync=False, ws=self._ws)       # (any stream) never touch it.  Warm-up: one-time attribute calls stay out of the capture
         torch.cuda.synchronize(ctx.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = ctx.encode(self.images, k, threshold, sync=False)
-        self._ws = ctx._ws                                                             # the captured launches point into this workspace: keep it alive
+            self.out = ctx.encode(self.images, self.k, self.threshold, sync=False, ws=self._ws)
+
+    def stale(self) -> bool:
+        """Has the module this graph was captured from moved on (new weights / dtype / device / layer selection)?"""
+        return self.tok is not None and self.tok._context() is not self.ctx
 
     def __call__(self, images: torch.Tensor):
         """-> (packed tokens (sum L_i, D) — a fresh tensor —, counts list, idx_cluster, score, index_down) like EncodeContext.encode."""
+        if self.stale():
+            self.graph = self.out = None
+            self._capture(self.tok._context())
         assert tuple(images.shape) == tuple(self.images.shape)
         self.images.copy_(images, non_blocking=True)
         self.graph.replay()

@@ -90,21 +90,36 @@ void setok_prof_end(hipStream_t s, int index) {
 // The record's work / bytes were computed for `rows_full` rows; the launch processes *rows_dev (<= rows_full) of them.  The count is copied to a
 // pinned word in stream order (it is final when the launch is enqueued), and setok_profile_stop scales work and the row-proportional bytes
 // (everything but `bytes_fixed`, the weight) by it: a launch sized for the worst case is never credited with rows it skipped.
+// The pinned words are slots of ONE ring allocated by setok_profile_start (a hipHostMalloc per launch is a synchronising allocation
+// inside the measured region and illegal under stream capture).  A launch that cannot be priced — ring exhausted, or the stream is being captured
+// into a graph (a device-to-host copy per replay is not what the caller asked to record) — has its record dropped rather than over-credited.
+namespace {
+constexpr int PROF_RING = 8192;
+int32_t* g_prof_ring = nullptr;
+int g_prof_ring_used = 0;
+}
 void setok_prof_rows(hipStream_t s, int index, const int32_t* rows_dev, int rows_full, double bytes_fixed) {
     if (index < 0 || !rows_dev || rows_full <= 0) return;
-    int32_t* h = nullptr;
-    if (hipHostMalloc((void**)&h, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (index >= (int)g_prof.size()) return;
+    if (capturing || !g_prof_ring || g_prof_ring_used >= PROF_RING) { g_prof[index].kind = -1; return; }
+    int32_t* h = g_prof_ring + g_prof_ring_used++;
     *h = rows_full;
     (void)hipMemcpyAsync(h, rows_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (index >= (int)g_prof.size()) { (void)hipHostFree(h); return; }
     g_prof[index].rows_host = h; g_prof[index].rows_full = rows_full; g_prof[index].bytes_fixed = bytes_fixed;
 }
 
 extern "C" int setok_profile_start(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); if (r.rows_host) (void)hipHostFree(r.rows_host); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
+    if (!g_prof_ring && hipHostMalloc((void**)&g_prof_ring, PROF_RING * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        g_prof_ring = nullptr;
+        (void)hipGetLastError();
+    }
+    g_prof_ring_used = 0;
     g_prof_on = 1;
     return SETOK_OK;
 }
@@ -125,7 +140,6 @@ extern "C" int setok_profile_stop(int* kind, int* cls, double* work, double* byt
         }
         if (ok && r.kind >= 0 && n < cap && kind && cls && work && bytes && ms) { kind[n] = r.kind; cls[n] = r.cls; work[n] = r.work; bytes[n] = r.bytes; ms[n] = t; ++n; }
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
-        if (r.rows_host) (void)hipHostFree(r.rows_host);
     }
     const int total = (int)g_prof.size() - dropped;
     g_prof.clear();

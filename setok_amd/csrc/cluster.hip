@@ -610,11 +610,14 @@ __global__ __launch_bounds__(512) void dpc_fused_kernel(FArgs g) {
 // An exchange = plain stores -> workgroup barrier -> ONE agent-scope release + a relaxed counter increment; the readers poll the counter (relaxed),
 // take ONE agent-scope acquire, and read with plain loads (cdna guide, Guideline 16).  Every strip writes whole 128-byte lines of its own; the
 // counters live in a line of their own.
-// Deadlock freedom without any assumption on dispatch order: the grid is PERSISTENT (at most one workgroup per CU: all co-resident) and pulls
-// (image, strip) items from queues in image-major order, so the strips of an image are taken by workgroups that are running at the same time;
-// whatever a workgroup waits for has either been pulled by a running workgroup or is next in a queue that workgroups finishing complete images keep
-// draining (at most 8 x 4 workgroups can ever hold items of incompletely pulled images).  One queue per XCD (images b = x mod 8, blocks x mod 8 —
-// observed placement, a speed matter only): the strips of an image re-read its x through ONE L2.
+// Deadlock freedom without any assumption on dispatch order: the grid is PERSISTENT (at most one workgroup per USABLE CU — the device's CU count
+// cut down to the stream's CU mask — so all of it is co-resident) and pulls (image, strip) items from Q queues in image-major order.  A queue has at
+// most ONE incompletely pulled image at any time, whose pulled strips (<= S - 1 of them) wait in their holders; every other held item belongs to a
+// completely pulled image, whose S holders are all running and need nobody else.  So at most Q (S - 1) workgroups can be waiting for an item nobody
+// has pulled, and the launch requires grid > Q (S - 1): Q = min(8, (grid - 1) / (S - 1)), which is >= 1 whenever grid >= S (checked on the host; a
+// device with fewer than S usable CUs is refused).  The round-3 code fixed Q = 8 without that check: a 32-CU partition at S = 5 could hang.
+// With Q = 8 a queue is an XCD's (images b = x mod 8, blocks x mod 8 — observed placement, a speed matter only): the strips of an image re-read its
+// x through ONE L2.
 // --------------------------------------------------------------------------------------------
 namespace {
 constexpr int SN = 576, SNT = SN / 16, SROWS = 128;
@@ -630,6 +633,7 @@ struct SArgs {
     int B, N, C, k, mcn, strips;
     float thr, sqrtC, inv_sqrtC;
     int scale_by_mul;
+    int nq;                                                 // number of item queues, 1..8: grid > nq (strips - 1)
 };
 
 __device__ inline void strip_publish(int* counter) {          // every thread's plain stores of the exchange are issued
@@ -669,19 +673,21 @@ __global__ __launch_bounds__(512) void dpc_strip_kernel(SArgs g) {
     const float INF = __builtin_inff();
     int* heads = reinterpret_cast<int*>(g.ws);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
-    const int home = blockIdx.x & 7;
+    const int nq = g.nq;
+    const int home = blockIdx.x % nq;
 
     for (;;) {
         // ---- next (image, strip): the home queue first, then the others ------------------------------------------------------------------------
         if (tid == 0) {
             int it = -1;
-            for (int o = 0; o < 8 && it < 0; ++o) {
-                const int x = (home + o) & 7;
-                const int per = (g.B - x + 7) / 8;                           // images x, x + 8, ... < B
+            for (int o = 0; o < nq && it < 0; ++o) {
+                int x = home + o;
+                if (x >= nq) x -= nq;
+                const int per = (g.B - x + nq - 1) / nq;                     // images x, x + nq, ... < B
                 if (per <= 0) continue;
                 if (__hip_atomic_load(heads + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per * S) continue;
                 const int q = __hip_atomic_fetch_add(heads + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (q < per * S) it = ((x + 8 * (q / S)) << 4) | (q % S);
+                if (q < per * S) it = ((x + nq * (q / S)) << 4) | (q % S);
             }
             *s_item = it;
         }
@@ -1297,11 +1303,31 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
             return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: cannot clear the exchange workspace");
         int ex = 0;
         const float mant = frexpf(sqrtC, &ex);
-        SArgs a{(const bf16*)x, noise, token_mask, idx_cluster, score, index_down, counts, vec_ws, B, N, C, k, min_cluster_num, strips, threshold, sqrtC,
-                1.0f / sqrtC, mant == 0.5f ? 1 : 0};
+        // persistent grid: never more workgroups than USABLE CUs (147 KiB of LDS each: one per CU, all co-resident).  The attribute is the device's
+        // (a CPX partition reports its own 32); a CU mask on the stream or the process (hipExtStreamCreateWithCUMask, ROC_GLOBAL_CU_MASK) cuts it down.
         int ncu = 256, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        const int grid = B * strips < ncu ? B * strips : ncu;          // persistent: never more workgroups than CUs (147 KiB of LDS each: one per CU, all co-resident)
+        {
+            uint32_t mask[32] = {0};
+            if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
+                int bits = 0;
+                for (int i = 0; i < 32; ++i) bits += __builtin_popcount(mask[i]);
+                if (bits > 0 && bits < ncu) ncu = bits;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (const char* e = getenv("SETOK_STRIP_GRID")) {                 // tests / small-device rehearsal: cap the grid (read per call)
+            const int cap = atoi(e);
+            if (cap > 0 && cap < ncu) ncu = cap;
+        }
+        const int grid = B * strips < ncu ? B * strips : ncu;
+        if (grid < strips)                                                // fewer co-resident workgroups than one image has strips: its exchanges could never complete
+            return setok_fail(SETOK_ELAUNCH, "setok_cluster_dpc_knn: %d usable workgroups cannot hold the %d strips of an image (N=%d)", grid, strips, N);
+        int nq = strips > 1 ? (grid - 1) / (strips - 1) : 8;             // grid > nq (strips - 1): see the deadlock-freedom note above the kernel
+        nq = nq > 8 ? 8 : nq;
+        SArgs a{(const bf16*)x, noise, token_mask, idx_cluster, score, index_down, counts, vec_ws, B, N, C, k, min_cluster_num, strips, threshold, sqrtC,
+                1.0f / sqrtC, mant == 0.5f ? 1 : 0, nq};
         if (token_mask) dpc_strip_kernel<true><<<grid, 512, S_LDS, s>>>(a); else dpc_strip_kernel<false><<<grid, 512, S_LDS, s>>>(a);
         SETOK_CHECK_LAUNCH("setok_cluster_dpc_knn(strips)");
         return SETOK_OK;

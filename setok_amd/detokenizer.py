@@ -347,11 +347,14 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
         return ops.layernorm(h, *pk["dec_ln"][:2], pk["dec_ln"][2], out=y)
 
     def forward(self, x, attention_masks: Optional[torch.Tensor] = None, return_stages: bool = False):
-        """Inference arithmetic (no autograd graph): refused loudly when gradients are enabled and a parameter or the tokens require one."""
+        """Inference arithmetic (no autograd graph).  With gradients enabled and a parameter or the tokens requiring one, the result carries a
+        grad_fn whose backward raises (autograd.no_backward): SeTok.forward-style callers that only read the reconstruction run, a
+        `loss.backward()` through the decoder says that it has no backward pass here."""
         from . import autograd
-        autograd.refuse_grad("SetokDeTokenizer.forward", [getattr(x, "packed", x) if not isinstance(x, (list, tuple)) else None, *(x if isinstance(x, (list, tuple)) else ()), *self.parameters()])
+        deps = [getattr(x, "packed", x) if not isinstance(x, (list, tuple)) else None, *(x if isinstance(x, (list, tuple)) else ()), *self.parameters()]
         with torch.no_grad():
-            return self._forward(x, attention_masks, return_stages)
+            out = self._forward(x, attention_masks, return_stages)
+        return autograd.no_backward("SetokDeTokenizer.forward", out, deps)
 
     def _forward(self, x, attention_masks: Optional[torch.Tensor] = None, return_stages: bool = False):
         """x: RaggedTokens (the tokenizer's output), a list of (L_i, D) tensors, or padded (B, L, D) with
@@ -401,12 +404,14 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
         'n (h w) (p q c) -> n c (h p) (w q)' rearrangement (ops.unpatchify)."""
         if self.to_pixels is None:
             raise RuntimeError("this SetokDeTokenizer was built without pixel_head=True: there is no `to_pixels` layer (the reference defines none)")
-        feats = self.forward(x, attention_masks)                                    # (B, Q, D); refuses a gradient like every inference module
+        from . import autograd
+        feats = self.forward(x, attention_masks)                                    # (B, Q, D)
         with torch.no_grad():
             B, Q, D = feats.shape
             pk = self._pack()
-            patches = ops.linear(feats.reshape(B * Q, D), *pk["pix"])
-            return ops.unpatchify(patches, B, self.height, self.weight, self.patch_size)
+            patches = ops.linear(feats.detach().reshape(B * Q, D), *pk["pix"])
+            img = ops.unpatchify(patches, B, self.height, self.weight, self.patch_size)
+        return autograd.no_backward("SetokDeTokenizer.decode_image", img, [feats, *self.to_pixels.parameters()])
 
     def reconstruction_loss(self, x, gold_image: torch.Tensor, attention_masks: Optional[torch.Tensor] = None, kind: str = "mse") -> torch.Tensor:
         """The pixel term of the reference's reconstruction objective between decode_image(x) and `gold_image` (B, 3, H, W) as a 0-d fp32 tensor:
@@ -415,5 +420,7 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
         img = self.decode_image(x, attention_masks)
         if tuple(gold_image.shape) != tuple(img.shape):
             raise ValueError(f"gold_image has shape {tuple(gold_image.shape)}, the decoder reconstructs {tuple(img.shape)}")
+        from . import autograd
         with torch.no_grad():
-            return ops.pixel_loss(img, gold_image.to(device=img.device, dtype=img.dtype).contiguous(), kind)
+            loss = ops.pixel_loss(img.detach(), gold_image.to(device=img.device, dtype=img.dtype).contiguous(), kind)
+        return autograd.no_backward("SetokDeTokenizer.reconstruction_loss", loss, [img])

@@ -93,11 +93,11 @@ class LlamaModel(PackCacheMixin, nn.Module):
 
     def forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None):
         """inputs_embeds (B, T, D); attention_mask (B, T), 1 = token (None = all); position_ids (B, T) (None = 0..T-1).
-        Returns the hidden states after the final norm, (B, T, D).  A prefill: inference arithmetic, no autograd graph (refused loudly when one
-        would be needed — training the LLM is the reference's HF-Trainer side, SURVEY.md §2 "OUT")."""
-        autograd.refuse_grad("LlamaModel.forward (the prefill has no backward pass on the HIP path)", [inputs_embeds, *self.parameters()])
+        Returns the hidden states after the final norm, (B, T, D).  A prefill: inference arithmetic, no autograd graph (where torch would have
+        recorded one the result's backward raises — training the LLM is the reference's HF-Trainer side, SURVEY.md §2 "OUT")."""
         with torch.no_grad():
-            return self._forward(inputs_embeds, attention_mask, position_ids)
+            out = self._forward(inputs_embeds, attention_mask, position_ids)
+        return autograd.no_backward("LlamaModel.forward (the prefill has no backward pass on the HIP path)", out, [inputs_embeds, *self.parameters()])
 
     def _forward(self, inputs_embeds, attention_mask=None, position_ids=None):
         B, T, D = inputs_embeds.shape
@@ -143,10 +143,9 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, labels=None, comp_images=None,
                 last_token_only: bool = False, return_loss: bool = False):
-        autograd.refuse_grad("SetokimLlamaPrefill.forward (inference: encode -> splice -> prefill -> logits)",
-                             [inputs_embeds, *self.parameters()])
         with torch.no_grad():
-            return self._forward(input_ids, attention_mask, position_ids, inputs_embeds, labels, comp_images, last_token_only, return_loss)
+            out = self._forward(input_ids, attention_mask, position_ids, inputs_embeds, labels, comp_images, last_token_only, return_loss)
+        return autograd.no_backward("SetokimLlamaPrefill.forward (inference: encode -> splice -> prefill -> logits)", out, [inputs_embeds, *self.parameters()])
 
     def _forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, labels=None, comp_images=None,
                  last_token_only: bool = False, return_loss: bool = False):

@@ -97,9 +97,9 @@ class Block(PackCacheMixin, nn.Module):
         """Block.forward (module.py:95-100) on packed rows `h` (rows, C), each row attending only within
         its own segment.  `h` is updated in place and returned.  Inference arithmetic; the differentiable form of the tokenizer's two
         Blocks is `SetokTokenizer.encode_features` (autograd.HeadFn)."""
-        autograd.refuse_grad("Block.forward_rows", [h, *self.parameters()], "Train the tokenizer's Blocks through SetokTokenizer.forward / encode_features.")
         with torch.no_grad():
-            return self._forward_rows(h, seg_offsets, n_segs, seg_len_bound)
+            out = self._forward_rows(h, seg_offsets, n_segs, seg_len_bound)
+        return autograd.no_backward("Block.forward_rows (train the tokenizer's Blocks through SetokTokenizer.forward / encode_features)", out, [h, *self.parameters()])
 
     def _forward_rows(self, h, seg_offsets, n_segs, seg_len_bound):
         pk = self._pack()
@@ -397,9 +397,9 @@ class SetokTokenizer(nn.Module):
             x = x.unsqueeze(0)
         B = x.shape[0]
         tower = self.image_feature_encoder
-        autograd.refuse_grad("SetokTokenizer.forward (no gradient flows to the images)", [x])
-        if tower.is_loaded:
-            autograd.refuse_grad("CLIPVisionTower (the ViT tower has no backward pass on the HIP path)", tower.vision_tower.parameters())
+        if tower.is_loaded:                                                        # images / tower parameters get no gradient, as in the reference (clip_encoder.py:50)
+            autograd.warn_no_grad_once("CLIPVisionTower", [x, *tower.vision_tower.parameters()],
+                                       "the tower's forward is @torch.no_grad() in the reference (clip_encoder.py:50) and has no backward pass on the HIP path")
         training_head = autograd.grad_needed(*[p for n, p in self.named_parameters() if not n.startswith("image_feature_encoder.")])
         if training_head or os.environ.get("SETOK_HOST_PATH", "0") == "1":        # SETOK_HOST_PATH: the same path op by op from Python (A/B runs, tests of the two forms)
             hidden = tower.hidden_rows(x)                                          # tokenizer.py:161
@@ -450,10 +450,12 @@ class SetokTokenizer(nn.Module):
         DataLoader workers): images (B, 3, H, W) -> (tokens, num_tokens) with tokens[i] = `gen_image` (L_i, D) of sample i and
         num_tokens[i] = L_i (the `target_num` of preprocess_multimodal).  Bit-identical to B single-image calls (the kernels'
         arithmetic per image does not depend on the batch), at the throughput of the batched path."""
-        feats, _, _ = self.forward(images, **kw)
+        with torch.no_grad():                                                      # dataset tensors: deterministic inference arithmetic whatever the module's mode (ADVICE r03)
+            feats, _, _ = self.forward(images, **kw)
         return feats, list(feats.counts)
 
     def encode(self, image: torch.Tensor, **kw) -> torch.Tensor:
         """Dataset-side contract (pairDataset.py:419-421): one image -> tokens (L, D); L = num_tokens."""
-        feats, _, _ = self.forward(image if image.dim() == 4 else image.unsqueeze(0), **kw)
+        with torch.no_grad():
+            feats, _, _ = self.forward(image if image.dim() == 4 else image.unsqueeze(0), **kw)
         return feats[0]

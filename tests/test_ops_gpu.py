@@ -661,3 +661,36 @@ def test_cluster_strips_full_batch_cfg4():
         one = ops.cluster_dpc_knn(xs[i], 1, N, 64, 0.125, 64)
         assert torch.equal(one[0][0], a[0][i]) and torch.equal(one[1][0], a[1][i]) and torch.equal(one[2][0], a[2][i]) and int(one[3][0]) == int(a[3][i]), i
     assert int(a[3].min()) >= 1 and int(a[0].max()) < int(a[3].max())
+
+
+@pytest.mark.parametrize("cap", [32, 33, 9, 5])
+def test_cluster_strips_on_a_small_grid_complete_and_keep_their_bits(cap):
+    """ADVICE r03 / VERDICT r03 item 6: the strips of an image spin-wait on each other, so the number of item queues must follow the number of
+    co-resident workgroups (grid > queues x (strips - 1)).  SETOK_STRIP_GRID caps the persistent grid the way a 32-CU partition or a CU mask would:
+    32 workgroups at 5 strips used to leave 4 home workgroups per queue waiting for a fifth strip nobody could pull.  The results must not depend
+    on the grid (every item's arithmetic is its own; the exchanges carry the same numbers)."""
+    B, N, C = 24, 576, 256
+    g = torch.Generator().manual_seed(5)
+    cent = torch.randn(30, C, generator=g) * 1.5
+    xs = (cent[torch.randint(0, 30, (B, N), generator=g)] + 0.2 * torch.randn(B, N, C, generator=g)).bfloat16().to(DEV)
+    full = ops.cluster_dpc_knn(xs.reshape(-1, C), B, N, 64, 0.125, 64)
+    torch.cuda.synchronize()
+    assert os.environ.get("SETOK_STRIP_GRID") is None
+    os.environ["SETOK_STRIP_GRID"] = str(cap)
+    try:
+        small = ops.cluster_dpc_knn(xs.reshape(-1, C), B, N, 64, 0.125, 64)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["SETOK_STRIP_GRID"]
+    assert all(torch.equal(u, v) for u, v in zip(full, small))
+
+
+def test_cluster_strips_refuse_a_grid_that_cannot_hold_one_image():
+    B, N, C = 2, 576, 64
+    xs = torch.randn(B * N, C).bfloat16().to(DEV)
+    os.environ["SETOK_STRIP_GRID"] = "4"                                   # 5 strips per image
+    try:
+        with pytest.raises(RuntimeError, match="usable workgroups"):
+            ops.cluster_dpc_knn(xs, B, N, 64, 0.125, 64)
+    finally:
+        del os.environ["SETOK_STRIP_GRID"]
