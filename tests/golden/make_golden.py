@@ -353,6 +353,78 @@ def gen_bf16_reference():
     save("bf16_reference", **arrs)
 
 
+def partition_drift(index_down_a, idx_a, index_down_b, idx_b):
+    """How far two clusterings of the same image are apart: (|L_a - L_b|, 1 - Jaccard of the centre-token sets, fraction of tokens whose
+    centre TOKEN differs — label ids shift with the centre list, centre tokens do not)."""
+    a, b = set(index_down_a.tolist()), set(index_down_b.tolist())
+    jacc = len(a & b) / float(len(a | b))
+    same = float((index_down_a[idx_a] == index_down_b[idx_b]).float().mean())
+    return abs(len(a) - len(b)), 1.0 - jacc, 1.0 - same
+
+
+def gen_bf16_tower():
+    """VERDICT r03 item 5 — the throughput mode's yardstick FROM PIXELS: the reference's own tower (HF CLIPVisionModel behind the reference's
+    CLIPVisionTower) AND head, cast to torch.bfloat16 as train_setokim.py:326 casts the module, run on CPU on the images of vitl_224.npz
+    (ViT-L/14-224, seeds 0 / 1 / 3) and of e2e_small.npz's recipe; stored: the reference-bf16 tower features (bf16 bit patterns), their
+    distance from the reference's fp32 features, and how far the reference's bf16 clustering drifts from its fp32 clustering (token count,
+    centre set, partition).  tests/test_fullsize_gpu.py holds the GPU's bf16 tower and clustering to 1.5 x these drifts."""
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    rms = lambda a, b: float(((a.double() - b.double()) ** 2).mean().sqrt() / (b.double() ** 2).mean().sqrt())
+    arrs = {}
+    # ---- ViT-L/14-224, 2 images (the inputs and fp32 outputs of vitl_224.npz) ----------------------------------------------------------
+    vc, hc = O.VitConfig(), O.HeadConfig(threshold=0.125)
+    tsd, hsd = O.init_tower_weights(vc, seed=0), O.init_head_weights(hc, seed=1)
+    d = R.make_clip_dir(vc.hidden_size, vc.num_hidden_layers, vc.num_attention_heads, vc.intermediate_size, vc.image_size, vc.patch_size, seed=0)
+    z = np.load(os.path.join(HERE, "vitl_224.npz"))
+    feats32 = torch.from_numpy(z["feats"])
+    images = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    for sel in (-2, -1):
+        tok = R.build_reference_tokenizer(d, hidden_dim=1024, token_feat_dim=4096, dim_feedforward=4096, min_cluster_num=64, threshold=0.125,
+                                          select_layer=sel)
+        full = dict(tsd); full.update(hsd)
+        load_weights_into(tok, full)
+        if sel == -2:
+            f32_feats, f32_res = feats32, [dict(index_down=torch.from_numpy(z[f"{i}:index_down"]).long(),
+                                                idx_cluster=torch.from_numpy(z[f"{i}:idx_cluster"]).long()) for i in range(2)]
+        else:                                                        # the launch scripts' layer selection: fp32 run here, features stored too
+            f32_feats, f32_res = R.rac_forward(tok, images, noise=None, return_stages=True)
+            arrs["vitl:sel-1:feats32"] = npy(f32_feats)
+            for i, r in enumerate(f32_res):
+                arrs[f"vitl:sel-1:{i}:index_down32"] = npy(r["index_down"]).astype(np.int32)
+                arrs[f"vitl:sel-1:{i}:idx_cluster32"] = npy(r["idx_cluster"]).astype(np.int32)
+        tok_b = tok.to(torch.bfloat16)
+        feats_b, res_b = R.rac_forward(tok_b, images.bfloat16(), noise=None, return_stages=True)
+        tag = f"vitl:sel{sel}"
+        arrs[tag + ":feats_bf16_bits"] = npy(feats_b.view(torch.int16))
+        arrs[tag + ":tower_err"] = np.array([rel(feats_b.float(), f32_feats), rms(feats_b.float(), f32_feats)])
+        print(f"  {tag}: reference-bf16 tower vs its fp32 tower: max-rel {rel(feats_b.float(), f32_feats):.3e}  rms-rel {rms(feats_b.float(), f32_feats):.3e}")
+        for i, r in enumerate(res_b):
+            dl, dj, dp = partition_drift(r["index_down"], r["idx_cluster"], f32_res[i]["index_down"], f32_res[i]["idx_cluster"])
+            arrs[f"{tag}:{i}:drift"] = np.array([dl, dj, dp])
+            arrs[f"{tag}:{i}:L"] = np.array([r["index_down"].numel(), f32_res[i]["index_down"].numel()])
+            print(f"  {tag}/img{i}: reference-bf16 L = {r['index_down'].numel()} (its fp32 run: {f32_res[i]['index_down'].numel()}); "
+                  f"1 - centre Jaccard {dj:.3f}; tokens with another centre {dp:.3f}")
+    # ---- small dims, the whole path (the tower of e2e_small's recipe), 4 images --------------------------------------------------------
+    tok = small_tok(sel=-2)
+    sdz = np.load(os.path.join(HERE, "e2e_small.npz"))
+    sd = {k[2:]: torch.from_numpy(sdz[k]) for k in sdz.files if k.startswith("w:")}
+    if sd:
+        load_weights_into(tok, sd)
+    images = torch.randn(4, 3, 112, 112, generator=torch.Generator().manual_seed(21))
+    thr = 0.5
+    f32_feats, f32_res = R.rac_forward(tok, images, threshold=thr, noise=None, return_stages=True)
+    arrs["small:w_keys"] = np.array(sorted(tok.state_dict().keys()))
+    for k_, v_ in tok.state_dict().items():
+        arrs["small:w:" + k_] = npy(v_)
+    tok_b = tok.to(torch.bfloat16)
+    feats_b, res_b = R.rac_forward(tok_b, images.bfloat16(), threshold=thr, noise=None, return_stages=True)
+    arrs["small:feats32"] = npy(f32_feats)
+    arrs["small:feats_bf16_bits"] = npy(feats_b.view(torch.int16))
+    arrs["small:tower_err"] = np.array([rel(feats_b.float(), f32_feats), rms(feats_b.float(), f32_feats)])
+    print(f"  small: reference-bf16 tower vs fp32: max-rel {rel(feats_b.float(), f32_feats):.3e}  rms-rel {rms(feats_b.float(), f32_feats):.3e}")
+    save("bf16_tower", **arrs)
+
+
 STAGE2_CASES = {
     # name: (projector_type, seed, B, T, V, token_feat_dim, hidden, kwargs, train_embed)
     "mlp2x": ("mlp2x_gelu", 11, 5, 12, 40, 96, 64, dict(), False),
@@ -493,6 +565,8 @@ if __name__ == "__main__":
         gen_stage2()
     if "bf16_reference" in which:
         gen_bf16_reference()
+    if "bf16_tower" in which:
+        gen_bf16_tower()
     if "detok" in which:
         gen_detok()
     if "splice" in which:

@@ -31,7 +31,7 @@ BF16_TOKEN_TOL = 1.0e-2   # bf16 throughput mode: tokens of the GPU head vs the 
                           # same cluster assignment; max-abs error relative to the largest token entry.  MEASURED (profiles/r03_bf16_parity.txt):
                           # 5.1e-3 at cfg2 dims (8 images), 5.2e-3 at cfg4 dims; the reference's own bf16 run sits at 5.2-5.7e-3 on the same
                           # stage (tests/golden/bf16_reference.npz) — the tolerance is 2 x the measured value (round 2 asserted 4e-2)
-BF16_TOWER_TOL = 5e-2     # bf16 tower features vs the fp32 oracle tower through 23 layers (measured 2.4e-2)
+# (the bf16 tower from pixels is held to 1.5 x the reference's own bf16 tower: tests/golden/bf16_tower.npz, measured 2.36e-2 max-rel / 1.24e-2 rms-rel)
 
 
 def _t(a):
@@ -159,35 +159,74 @@ def test_cfg2_bf16_contract_on_the_gpus_own_features():
     assert s["tokens_equal"] >= s["tokens_certain"]
 
 
-def test_cfg2_bf16_tower_and_partition_agreement_floors():
-    """Throughput mode (bf16 end to end) against the fp32 oracle FROM PIXELS on the same seeded weights / images.  The clustering is
-    discontinuous in its input and bf16 tower features are a different input (2e-2 relative), so integers cannot be demanded here; what
-    is asserted are floors on how far the result may drift: tower error, token counts, centre-set overlap and partition agreement."""
-    vc, hc = O.VitConfig(), O.HeadConfig(threshold=0.125)
-    sd = O.init_tower_weights(vc, 0); sd.update(O.init_head_weights(hc, 1))
-    g = torch.Generator().manual_seed(3)
-    images = torch.randn(2, 3, 224, 224, generator=g)
+def _drift(index_down_a, idx_a, index_down_b, idx_b):
+    """(|L_a - L_b|, 1 - Jaccard of the centre-token sets, fraction of tokens whose centre TOKEN differs) — as tests/golden/make_golden.py's
+    partition_drift measures the reference's own bf16 run against its fp32 run."""
+    a, b = set(index_down_a.tolist()), set(index_down_b.tolist())
+    return abs(len(a) - len(b)), 1.0 - len(a & b) / float(len(a | b)), 1.0 - float((index_down_a[idx_a] == index_down_b[idx_b]).float().mean())
+
+
+@pytest.mark.parametrize("sel", [-2, -1])
+def test_cfg2_bf16_from_pixels_drifts_no_further_than_the_references_own_bf16_run(golden_dir, sel):
+    """Throughput mode (bf16 end to end) FROM PIXELS against the reference's fp32 run on the same seeded weights / images.
+    The yardstick is the REFERENCE'S OWN bf16 run from pixels (tests/golden/bf16_tower.npz: HF CLIP tower + the reference head cast to
+    torch.bfloat16 on CPU, train_setokim.py:326):
+      * tower: |GPU bf16 features - reference fp32 features| <= 1.5 x |reference bf16 features - reference fp32 features| (max-rel and rms-rel);
+        this is the gemm_pp + LayerNorm-fold + attn_vit chain that is 95 % of the timed step;
+      * clustering (discontinuous in its input, so integers cannot be demanded from a 2e-2-perturbed input): token count, centre set and
+        partition drift from the fp32 run <= 1.5 x the largest drift the reference's bf16 run shows on these images (round 3 asserted loose
+        floors: counts within 20 %, Jaccard >= 0.5, same-centre >= 0.4).
+    sel = -2: the reference classes' default layer; sel = -1: what the launch scripts pass (bench.py's headline)."""
+    zt = np.load(os.path.join(golden_dir, "bf16_tower.npz"))
+    if sel == -2:
+        z = np.load(os.path.join(golden_dir, "vitl_224.npz"))
+        feats32 = _t(z["feats"])
+        ref32 = [(_t(z[f"{i}:index_down"]).long(), _t(z[f"{i}:idx_cluster"]).long()) for i in range(2)]
+    else:
+        feats32 = _t(zt["vitl:sel-1:feats32"])
+        ref32 = [(_t(zt[f"vitl:sel-1:{i}:index_down32"]).long(), _t(zt[f"vitl:sel-1:{i}:idx_cluster32"]).long()) for i in range(2)]
+    tag = f"vitl:sel{sel}"
+    ref_max, ref_rms = zt[tag + ":tower_err"].tolist()
+    ref_drift = np.stack([zt[f"{tag}:{i}:drift"] for i in range(2)]).max(axis=0)          # the reference-bf16 run's worst image, per measure
+    images = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3))
     tok = _vitl_tok(dtype=torch.bfloat16)
+    tok.image_feature_encoder.select_layer = sel
     hidden = tok.image_feature_encoder.hidden_rows(images.to(DEV))
     toks, idx, score, st = tok.encode_features(hidden, 2, return_stages=True)
     feats = tok.image_feature_encoder(images.to(DEV).bfloat16()).float().cpu()
-    feats_ref, ref = O.encode(sd, vc, hc, images)
-    ferr = _rel(feats, feats_ref)
-    stats = []
+    rms = lambda a, b: float(((a.double() - b.double()) ** 2).mean().sqrt() / (b.double() ** 2).mean().sqrt())
+    got_max, got_rms = _rel(feats, feats32), rms(feats, feats32)
+    ref_bits = torch.from_numpy(zt[tag + ":feats_bf16_bits"]).view(torch.bfloat16).float()
+    print(f"bf16 tower from pixels (select_layer {sel}): GPU vs reference-fp32 max-rel {got_max:.3e} rms-rel {got_rms:.3e}; "
+          f"reference-bf16 vs reference-fp32 max-rel {ref_max:.3e} rms-rel {ref_rms:.3e}; GPU vs reference-bf16 rms-rel {rms(feats, ref_bits):.3e}")
+    assert got_max <= BF16_VS_REFERENCE * ref_max and got_rms <= BF16_VS_REFERENCE * ref_rms
     for i in range(2):
         L = st["counts"][i]
-        mine = st["index_down"][i, :L].cpu()
-        theirs = ref[i].index_down
-        inter = len(set(mine.tolist()) & set(theirs.tolist()))
-        jacc = inter / float(len(set(mine.tolist()) | set(theirs.tolist())))
-        same_centre = float((mine[idx[i].cpu()] == theirs[ref[i].idx_cluster]).float().mean())      # token -> centre TOKEN (label ids shift)
-        stats.append(dict(L=L, L_ref=int(theirs.numel()), centre_jaccard=round(jacc, 3), same_centre=round(same_centre, 3)))
-    print(f"bf16 vs fp32 oracle from pixels: tower feature rel err {ferr:.3e}; {stats}")
-    assert ferr < BF16_TOWER_TOL
-    for s in stats:
-        assert abs(s["L"] - s["L_ref"]) <= max(3, 0.2 * s["L_ref"])
-        assert s["centre_jaccard"] >= 0.5 and s["same_centre"] >= 0.4
+        dl, dj, dp = _drift(st["index_down"][i, :L].cpu(), idx[i].cpu(), *ref32[i])
+        print(f"  image {i}: L = {L} (reference fp32 {ref32[i][0].numel()}, reference bf16 {int(zt[f'{tag}:{i}:L'][0])}); 1 - centre Jaccard {dj:.3f} "
+              f"(reference-bf16 worst {ref_drift[1]:.3f}); tokens with another centre {dp:.3f} (reference-bf16 worst {ref_drift[2]:.3f})")
+        assert dl <= BF16_VS_REFERENCE * ref_drift[0] and dj <= BF16_VS_REFERENCE * ref_drift[1] and dp <= BF16_VS_REFERENCE * ref_drift[2], (i, dl, dj, dp, ref_drift)
     assert all(t.shape[1] == 4096 and torch.isfinite(t.float()).all() for t in toks)
+
+
+def test_small_dims_bf16_tower_from_pixels_against_the_references_bf16_tower(golden_dir):
+    """The same yardstick at small dims with the weights in the fixture (the whole tower, 4 images): GPU bf16 features no further from the
+    reference's fp32 features than 1.5 x the reference's own bf16 tower."""
+    zt = np.load(os.path.join(golden_dir, "bf16_tower.npz"))
+    sd = {k[len("small:w:"):]: _t(zt[k]) for k in zt.files if k.startswith("small:w:")}
+    vc = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=112, patch_size=14)
+    tok = SetokTokenizer(vision_tower=vc, mm_vision_select_layer=-2, hidden_dim=64, token_feat_dim=96, min_cluster_num=8, threshold=0.5, nheads=2,
+                         dim_feedforward=128)
+    assert not tok.load_state_dict(sd, strict=False).unexpected_keys
+    tok = tok.to(device=DEV, dtype=torch.bfloat16).eval()
+    images = torch.randn(4, 3, 112, 112, generator=torch.Generator().manual_seed(21))
+    feats = tok.image_feature_encoder(images.to(DEV).bfloat16()).float().cpu()
+    feats32 = _t(zt["small:feats32"])
+    rms = lambda a, b: float(((a.double() - b.double()) ** 2).mean().sqrt() / (b.double() ** 2).mean().sqrt())
+    ref_max, ref_rms = zt["small:tower_err"].tolist()
+    got_max, got_rms = _rel(feats, feats32), rms(feats, feats32)
+    print(f"small dims bf16 tower: GPU max-rel {got_max:.3e} rms-rel {got_rms:.3e}; reference-bf16 max-rel {ref_max:.3e} rms-rel {ref_rms:.3e}")
+    assert got_max <= BF16_VS_REFERENCE * ref_max and got_rms <= BF16_VS_REFERENCE * ref_rms
 
 
 # ======================================================================================================================================

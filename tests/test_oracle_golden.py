@@ -359,3 +359,44 @@ def test_pixel_head_restatement():
     a, b = torch.randn(B, 3, 28, 35, generator=g), torch.randn(B, 3, 28, 35, generator=g)
     assert torch.allclose(O.pixel_loss(a, b, "mse"), torch.nn.functional.mse_loss(a, b), rtol=1e-6)
     assert torch.allclose(O.pixel_loss(a, b, "l1"), torch.nn.functional.l1_loss(a, b), rtol=1e-6)
+
+
+# ---- a second opinion on the ONE parity-unpinned sub-stage: the pixel decoder's timm Block (detokenizer.py:6,49-51) ---------------------------
+def test_vit_block_restatement_against_an_independent_implementation():
+    """`oracle.vit_block_forward` restates timm==0.9.16's `vision_transformer.Block` from its published algorithm (timm is not installable
+    here, pyproject.toml:22): the restatement AND the HIP kernel were written by the same hand, so this sub-stage was single-sourced
+    (VERDICT r03 weak 2).  HuggingFace `transformers` ships an independent implementation of the same block — `ViTLayer`: pre-LN, separate
+    q / k / v projections, softmax(q k^T / sqrt(d_h)) v, output projection, residual; LayerNorm, Linear -> GELU (erf) -> Linear, residual.
+    timm's fused `qkv` Linear is the row-wise concatenation [q; k; v] of HF's three.  This does NOT pin parity (it is not timm), but a
+    misremembered block structure — post-LN, scale placement, tanh-GELU, a LayerScale, the head split order — would show here."""
+    import torch
+    from transformers import ViTConfig
+    from transformers.models.vit.modeling_vit import ViTLayer
+    import setok_oracle as O
+    for hidden, heads, inter, eps, seed in ((64, 4, 256, 1e-6, 0), (96, 6, 192, 1e-5, 1)):
+        torch.manual_seed(seed)
+        cfg = ViTConfig(hidden_size=hidden, num_hidden_layers=1, num_attention_heads=heads, intermediate_size=inter, hidden_act="gelu",
+                        layer_norm_eps=eps, qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
+        layer = ViTLayer(cfg).eval()
+        with torch.no_grad():
+            for prm in layer.parameters():                                        # biases and LayerNorm affine away from their 0 / 1 defaults
+                prm.copy_(torch.randn_like(prm) * (0.3 if prm.dim() == 1 else hidden ** -0.5))
+            layer.layernorm_before.weight.add_(1.0); layer.layernorm_after.weight.add_(1.0)
+        h = layer.state_dict()
+        p = "pixel_decoder.0."
+        sd = {p + "norm1.weight": h["layernorm_before.weight"], p + "norm1.bias": h["layernorm_before.bias"],
+              p + "attn.qkv.weight": torch.cat([h["attention.q_proj.weight"], h["attention.k_proj.weight"], h["attention.v_proj.weight"]], 0),
+              p + "attn.qkv.bias": torch.cat([h["attention.q_proj.bias"], h["attention.k_proj.bias"], h["attention.v_proj.bias"]], 0),
+              p + "attn.proj.weight": h["attention.o_proj.weight"], p + "attn.proj.bias": h["attention.o_proj.bias"],
+              p + "norm2.weight": h["layernorm_after.weight"], p + "norm2.bias": h["layernorm_after.bias"],
+              p + "mlp.fc1.weight": h["mlp.fc1.weight"], p + "mlp.fc1.bias": h["mlp.fc1.bias"],
+              p + "mlp.fc2.weight": h["mlp.fc2.weight"], p + "mlp.fc2.bias": h["mlp.fc2.bias"]}
+        x = torch.randn(3, 17, hidden)
+        with torch.no_grad():
+            want = layer(x)
+            want = want[0] if isinstance(want, (tuple, list)) else want
+        got = O.vit_block_forward(sd, p, x, heads, eps)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+        # and the comparison can fail: the same weights with the head split transposed (heads-major vs qkv-major) or tanh-GELU do not match
+        bad = dict(sd); bad[p + "attn.qkv.weight"] = sd[p + "attn.qkv.weight"].reshape(3, heads, hidden // heads, hidden).transpose(0, 1).reshape(3 * hidden, hidden)
+        assert (O.vit_block_forward(bad, p, x, heads, eps) - want).abs().max() > 1e-2
