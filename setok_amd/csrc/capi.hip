@@ -50,6 +50,10 @@ thread_local std::vector<int> g_open;               // indices of this thread's 
 bool setok_prof_on() { return g_prof_on != 0; }
 
 int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes, bool attach) {
+    {   // a launch that is being CAPTURED into a graph is not measured: an event recorded under capture belongs to the graph and has no time of its own
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return -1;
+    }
     ProfRec r{kind, cls, work, bytes, nullptr, nullptr, attach, false, false, nullptr, 0, 0.0};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
     if (!attach) { (void)hipEventRecord(r.e0, s); r.started = true; }
