@@ -53,6 +53,54 @@ __global__ __launch_bounds__(1024) void bw_kernel(const char* src, int iters, fl
     if (acc[0] == 12345.678f) sink[0] = acc[0];
 }
 
+
+// GEMM-shaped access: a workgroup streams a 256-row operand panel K-tile by K-tile — per K-tile 256 rows x 128 bytes, a wave-request = 8 rows x 128 B,
+// row pitch `pitch` bytes — the 32 workgroups of an XCD walk 4 panels (8 share one: L2-resident after the first pass).  Question: does the ROW PITCH
+// (2 KiB for K = 1024, 8 KiB for K = 4096, 16 KiB for 8192^3) decide how many L2 channels a K-tile's 256 lines fall on?
+template <int DEPTH>
+__global__ __launch_bounds__(256) void panel_kernel(const char* src, int pitch, int ktiles, int passes, unsigned long long* cycles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t panel_bytes = (size_t)256 * pitch;
+    const char* pan = src + ((size_t)(blockIdx.x & 7) * 4 + ((blockIdx.x >> 3) & 3)) * panel_bytes;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * (DEPTH * 1024);
+    const unsigned voff = (unsigned)(tid & 63) / 8u * (unsigned)pitch + ((unsigned)(tid & 7) << 4);        // 8 rows x 8 slots of 16 B
+    int d = 0;
+    for (int ps = 0; ps < passes; ++ps)
+        for (int t = 0; t < ktiles; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned long long b = (unsigned long long)(pan + (size_t)(i * 32 + wave * 8) * pitch + (size_t)t * 128);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+                const unsigned long long sb = (unsigned long long)lo | ((unsigned long long)hi << 32);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sb), "s"(lds0 + (d % DEPTH) * 1024) : "memory");
+                if (++d % (DEPTH / 2) == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH / 2) : "memory");
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) cycles[blockIdx.x] = 0;
+}
+
+static void run_panel(const char* d_src, int pitch, unsigned long long* d_cyc, int ncu) {
+    constexpr int DEPTH = 16;
+    const int ktiles = 16, passes = 64;
+    const size_t lds = (size_t)4 * DEPTH * 1024;
+    CK(hipFuncSetAttribute((const void*)panel_kernel<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0));
+        panel_kernel<DEPTH><<<ncu, 256, lds>>>(d_src, pitch, ktiles, passes, d_cyc);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double bytes_per_cu = (double)passes * ktiles * 256 * 128.0;
+    printf("panel walk, row pitch %6d B (K-tile = 256 rows x 128 B, 16 KiB in flight per wave): %7.1f GB/s per CU  %6.2f TB/s chip\n", pitch,
+           bytes_per_cu / (best * 1e-3) / 1e9, bytes_per_cu * ncu / (best * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 template <int DEPTH, bool TO_LDS>
 static void run(const char* d_src, int nw, float* sink, unsigned long long* d_cyc, int ncu) {
     const int iters = 4096 / DEPTH;
@@ -81,8 +129,11 @@ static void run(const char* d_src, int nw, float* sink, unsigned long long* d_cy
 int main() {
     int ncu = 256; { hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); ncu = p.multiProcessorCount; }
     char* d_src; float* sink; unsigned long long* d_cyc;
-    CK(hipMalloc(&d_src, (size_t)8 * WINDOW)); CK(hipMemset(d_src, 1, (size_t)8 * WINDOW));
+    const size_t src_bytes = (size_t)32 * 256 * (16384 + 256);        // 32 panels at the largest pitch
+    CK(hipMalloc(&d_src, src_bytes)); CK(hipMemset(d_src, 1, src_bytes));
     CK(hipMalloc(&sink, 64)); CK(hipMalloc(&d_cyc, ncu * 8));
+    for (int pitch : {2048, 2048 + 128, 2048 + 256, 6144, 8192, 8192 + 128, 16384, 16384 + 128}) run_panel(d_src, pitch, d_cyc, ncu);
+    if (getenv("PANEL_ONLY")) return 0;
     for (int nw : {4, 8, 16}) {
         run<2, true>(d_src, nw, sink, d_cyc, ncu);
         run<4, true>(d_src, nw, sink, d_cyc, ncu);
