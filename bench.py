@@ -94,7 +94,7 @@ def build_model(device, img=IMG, dtype=torch.bfloat16, select_layer=-1):
     return tok.to(device=device, dtype=dtype).eval(), proj.to(device=device, dtype=dtype).eval()
 
 
-def cpu_baseline(tok, proj, n_images=16, reps=3):
+def cpu_baseline(tok, proj, n_images=16, reps=3, select_layer=-1):
     """Oracle (oracle/setok_oracle.py) on the host cores: fp32, same weights (upcast from the bf16 model),
     same synthetic image distribution, micro-batch of `n_images`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -107,7 +107,7 @@ def cpu_baseline(tok, proj, n_images=16, reps=3):
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in tok.state_dict().items()}
     psd = {k: v.detach().float().cpu() for k, v in proj.state_dict().items()}
-    vc, hc = O.VitConfig(), O.HeadConfig(threshold=THRESHOLD)
+    vc, hc = O.VitConfig(), O.HeadConfig(threshold=THRESHOLD, mm_vision_select_layer=select_layer)     # the same layer selection as the timed GPU steps
     g = torch.Generator().manual_seed(3)
     images = torch.randn(n_images, 3, IMG, IMG, generator=g)
     t0 = time.perf_counter()
@@ -123,7 +123,7 @@ def cpu_baseline(tok, proj, n_images=16, reps=3):
         out = O.encode_images(sd, psd, "mlp2x_gelu", vc, hc, images)
     dt = time.perf_counter() - t0
     return dict(value=round(n_images * reps / dt, 3), unit="images/s", cores=cores, kind="port",
-                sample=f"{reps} x {n_images} images of the same workload (fp32, torch CPU, {cores} threads, {dt:.1f} s); "
+                sample=f"{reps} x {n_images} images of the same workload (select_layer {select_layer}, fp32, torch CPU, {cores} threads, {dt:.1f} s); "
                        f"tokens/img {sum(o.shape[0] for o in out) / n_images:.1f}")
 
 
@@ -474,7 +474,7 @@ def main():
         if llm is not None:
             res["config"]["lm_loss"] = round(float(step.loss), 6)
         if not args.no_cpu_baseline and not args.timed_only and world == 1 and args.workload == "cfg2":
-            res["cpu_baseline"] = cpu_baseline(tok, proj)
+            res["cpu_baseline"] = cpu_baseline(tok, proj, select_layer=args.select_layer)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

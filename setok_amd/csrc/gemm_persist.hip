@@ -548,66 +548,111 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
 #pragma unroll
         for (int i = 0; i < NJ; ++i) dma16(b_src[i] + k0, sb + TTM * TK * 2 + i * 4096);
     };
-    for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) issue(kt);
+    // The K loop used to be latency-serial per K-tile (4 waves, one per SIMD: counted wait -> barrier release ~80 cycles -> ds_read latency -> a
+    // handful of MFMAs): ~590 cycles per K-tile at the 32 x 32 shape against 64 of MFMA issue — and the launches of one image are exactly this loop
+    // (tools/latency.py).  Round 4, eight-stage shapes: the K-tiles go through the loop in PAIRS — one counted wait, one barrier, one round of
+    // fragment-read latency per TWO K-tiles (the compiler hoists the pair's reads above its MFMAs; NS - 4 K-tiles stay in flight beyond the pair).
+    // M = 257: fc2 (K = 4096) 17.9 -> 13.6 us, q|k|v 7.7 -> 6.8, proj 6.2 -> 5.6; one image 1.82 -> 1.67 ms (profiles/r04_small_gemm_pairs.log).
+    // A second version that also read the NEXT pair's fragments under the current pair's MFMAs (two register sets, the pair's stages refilled one
+    // barrier earlier) was slower than this one (fc2 15.8 us, one image 1.75 ms) and is not kept.  The MFMA order — K-tile kt, then kt + 1, each
+    // k-step 0 then 1 — is unchanged: bits identical to every other bf16 GEMM kernel.
+    constexpr bool PAIR = NS >= 8;
+    for (int kt = 0; kt < (PAIR ? NS - 2 : NS - 1) && kt < nk; ++kt) issue(kt);
 
     f32x4 acc[NI][NJ];                                      // this wave's (TTM / 2) x (TTN / 2): NI x NJ MFMA tiles of 16 x 16
-    for (int kt = 0; kt < nk; ++kt) {
-        // K-tile kt has landed for this wave: at most the LPT * min(NS - 2, nk - 1 - kt) younger loads may still fly
-        switch (min(NS - 2, nk - 1 - kt)) {
-            case 6: wait_vm<LPT * 6>(); break;
-            case 5: wait_vm<LPT * 5>(); break;
-            case 4: wait_vm<LPT * 4>(); break;
-            case 3: wait_vm<LPT * 3>(); break;
-            case 2: wait_vm<LPT * 2>(); break;
-            case 1: wait_vm<LPT>(); break;
-            default: wait_vm<0>(); break;
-        }
-        s_barrier_lgkm();                                   // everyone's pieces; everyone is done with the stage of K-tile kt - 1 ...
-        if (kt + NS - 1 < nk) issue(kt + NS - 1);           // ... which is the stage K-tile kt + NS - 1 goes to
-        if (kt == 0) {
-            if constexpr (LNK) {                                // the same fragments, the same instruction as the persistent kernel: identical bits
-                f32x4 z;
+    auto init_acc = [&]() {
+        if constexpr (LNK) {                                // the same fragments, the same instruction as the persistent kernel: identical bits
+            f32x4 z;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) z[e] = 0.f;
-                bf16x8 cfr[NJ];
+            for (int e = 0; e < 4; ++e) z[e] = 0.f;
+            bf16x8 cfr[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) cfr[j] = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 128)[wn * (TTN / 2) + j * 16 + l15], g4);
+            for (int j = 0; j < NJ; ++j) cfr[j] = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 128)[wn * (TTN / 2) + j * 16 + l15], g4);
 #pragma unroll
-                for (int t = 0; t < NI; ++t) {
-                    const bf16x8 rfr = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 384)[wm * (TTM / 2) + t * 16 + l15], g4);
+            for (int t = 0; t < NI; ++t) {
+                const bf16x8 rfr = ln_frag_lane(reinterpret_cast<const f32x4*>(sbias + 384)[wm * (TTM / 2) + t * 16 + l15], g4);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float b = sbias[wn * (TTN / 2) + j * 16 + 4 * g4 + e];
-#pragma unroll
-                        for (int t = 0; t < NI; ++t) acc[t][j][e] = b;
-                    }
+                for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b = sbias[wn * (TTN / 2) + j * 16 + 4 * g4 + e];
+#pragma unroll
+                    for (int t = 0; t < NI; ++t) acc[t][j][e] = b;
+                }
         }
+    };
+    auto read_frags = [&](int kt, bf16x8 (&af)[2][NI], bf16x8 (&wf)[2][NJ]) {
         const char* Ab = smem + (kt % NS) * STG;
         const char* Bb = Ab + TTM * TK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[NJ], af[NI];
 #pragma unroll
             for (int t = 0; t < NI; ++t) {
                 const int ra = wm * (TTM / 2) + t * 16 + l15;
-                af[t] = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 4 + g4) ^ swz(ra)) << 4));
+                af[ks][t] = *reinterpret_cast<const bf16x8*>(Ab + ra * 128 + (((ks * 4 + g4) ^ swz(ra)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int rb = wn * (TTN / 2) + j * 16 + l15;
-                wf[j] = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 4 + g4) ^ swz(rb)) << 4));
+                wf[ks][j] = *reinterpret_cast<const bf16x8*>(Bb + rb * 128 + (((ks * 4 + g4) ^ swz(rb)) << 4));
             }
+        }
+    };
+    auto mma_ktile = [&](const bf16x8 (&af)[2][NI], const bf16x8 (&wf)[2][NJ]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int t = 0; t < NI; ++t)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[t], acc[t][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][t], acc[t][j], 0, 0, 0);
+    };
+    if constexpr (PAIR) {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            // K-tiles kt and kt + 1 have landed for this wave: at most the LPT * min(NS - 4, nk - 2 - kt) younger loads may still fly
+            switch (min(NS - 4, nk - 2 - kt)) {
+                case 4: wait_vm<LPT * 4>(); break;
+                case 3: wait_vm<LPT * 3>(); break;
+                case 2: wait_vm<LPT * 2>(); break;
+                case 1: wait_vm<LPT>(); break;
+                default: wait_vm<0>(); break;
+            }
+            s_barrier_lgkm();                               // everyone's pieces; everyone is done with the stages of K-tiles kt - 2, kt - 1 ...
+            if (kt + NS - 2 < nk) issue(kt + NS - 2);       // ... which are the stages K-tiles kt + NS - 2, kt + NS - 1 go to
+            if (kt + NS - 1 < nk) issue(kt + NS - 1);
+            if (kt == 0) init_acc();
+            bf16x8 af0[2][NI], wf0[2][NJ], af1[2][NI], wf1[2][NJ];
+            read_frags(kt, af0, wf0);
+            read_frags(kt + 1, af1, wf1);
+            mma_ktile(af0, wf0);
+            mma_ktile(af1, wf1);
+        }
+        if (kt < nk) {                                      // an odd number of K-tiles: the last one alone (nothing younger is in flight)
+            wait_vm<0>();
+            s_barrier_lgkm();
+            if (kt == 0) init_acc();
+            bf16x8 af0[2][NI], wf0[2][NJ];
+            read_frags(kt, af0, wf0);
+            mma_ktile(af0, wf0);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            // K-tile kt has landed for this wave: at most the LPT * min(NS - 2, nk - 1 - kt) younger loads may still fly
+            switch (min(NS - 2, nk - 1 - kt)) {
+                case 2: wait_vm<LPT * 2>(); break;
+                case 1: wait_vm<LPT>(); break;
+                default: wait_vm<0>(); break;
+            }
+            s_barrier_lgkm();                               // everyone's pieces; everyone is done with the stage of K-tile kt - 1 ...
+            if (kt + NS - 1 < nk) issue(kt + NS - 1);       // ... which is the stage K-tile kt + NS - 1 goes to
+            if (kt == 0) init_acc();
+            bf16x8 af0[2][NI], wf0[2][NJ];
+            read_frags(kt, af0, wf0);
+            mma_ktile(af0, wf0);
         }
     }
     // epilogue: the TTM x TTN tile is transposed through stage 0 (every load has landed; the barrier orders the last reads); rows of 2 * TTN bytes
