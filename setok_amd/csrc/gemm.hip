@@ -256,7 +256,7 @@ int setok_linear_dev(void* stream, int dtype, int out_dtype, const void* A, int6
         static const bool env_small = [] { const char* e = getenv("SETOK_GEMM_SMALL_TILES"); return e && e[0] == '1'; }();
         g_force_small_tiles = env_small;
     }
-    static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();   // test hook
+    static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 90; }();   // test hook; round 4: 48 -> 90 (the pair-wise small-tile kernel moved the crossover: profiles/r04_mintiles.log)
     static const int small_max = [] { const char* e = getenv("SETOK_GEMM_SMALL64_MAXTILES"); return e ? atoi(e) : 0x7fffffff; }();
     // the launches of gemm_persist.hip (every bf16 -> bf16 problem with aligned rows, unless a test hook says otherwise) carry the profiler's timestamps themselves
     const bool lds_dma_path = dtype == SETOK_BF16 && out_dtype == SETOK_BF16 && batch == 1 && K % BK == 0 && lda % 8 == 0 && N % 64 == 0 && ldc % 8 == 0 && !g_force_small_tiles &&
@@ -268,7 +268,7 @@ int setok_linear_dev(void* stream, int dtype, int out_dtype, const void* A, int6
     if (dtype == SETOK_BF16) {
         SETOK_CHECK_ARG(K % BK == 0, "setok_linear(bf16): K=%d must be a multiple of %d", K, BK);
         SETOK_CHECK_ARG(lda % 8 == 0, "setok_linear(bf16): lda must be a multiple of 8");
-        // big problems (>= 48 tiles of 256x256; measured crossover against the 64x64 kernel: ~50 tiles): persistent direct-to-LDS kernel (gemm_persist.hip)
+        // big problems (>= 90 tiles of 256x256; measured crossover against the 64x64 kernel: 60 and 80 tiles are faster there, 96 here): persistent direct-to-LDS kernel (gemm_persist.hip)
         if (out_dtype == SETOK_BF16 && batch == 1 && N % 64 == 0 && K >= 192 && ldc % 8 == 0 && cdiv(M, 256) * cdiv(N, 256) >= persist_min && !g_force_small_tiles)
             return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)W, bias, (const bf16*)residual, (bf16*)C, ldc, M, N, K, act, nullptr, nullptr, m_dev);
         // fp32-out batched problems without bias / activation / residual and with enough tiles (weight-gradient partial products)
@@ -316,7 +316,7 @@ extern "C" int setok_linear_ln(void* stream, const void* A, int64_t lda, const v
     if (M == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     SetokProfScope prof(s, SETOK_PROF_GEMM_BF16, act | 8, 2.0 * M * N * K, ((double)M * K + (double)N * K) * 2.0 + (double)M * N * 2.0 + (double)M * 32.0, true);
-    static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 48; }();
+    static const int persist_min = [] { const char* e = getenv("SETOK_GEMM_PERSIST_MINTILES"); return e ? atoi(e) : 90; }();
     if (K >= 192 && cdiv(M, 256) * cdiv(N, 256) >= persist_min)
         return setok_gemm_persist_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag, nullptr);
     return setok_gemm_small_bf16(s, (const bf16*)A, lda, (const bf16*)w_gamma, nullptr, nullptr, (bf16*)C, ldc, M, N, K, act, row_stats, col_frag, nullptr);
