@@ -15,6 +15,16 @@
 
 namespace {
 
+int cu_count() {                       // of the CURRENT device
+    static SetokPerDevice<int> cache;
+    int n = 256;
+    cache.get(n, [](int& v) {
+        int dev = 0;
+        return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0;
+    });
+    return n;
+}
+
 #ifndef ATTN_STAGE_SBASE
 #define ATTN_STAGE_SBASE 1
 #endif
@@ -127,7 +137,12 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     // (The class-token tile — T = 32k + 1 — costs wave 0 a second pass.  Splitting that tile's keys across the waves and
     // merging partial softmaxes through LDS was tried twice: no gain, the kernel is bound by the total number of
     // (q-tile, kv-tile) units per SIMD, and the second workgroup on the CU fills the idle waves' issue slots.)
-    for (int qt = wave; qt < nq; qt += NW) {
+    // Query tiles -> (workgroup z of gridDim.z, wave): tile t is taken by wave t / QS of workgroup t % QS.  QS = 1 (every launch with enough (image,
+    // head) pairs to fill the chip): wave w takes tiles w, w + NW, ...  A handful of images (round 4): QS > 1 workgroups per (image, head), each
+    // staging the head's K / V (L2 hits after the first) and taking every QS-th tile — 16 workgroups of nine tiles each cannot occupy 256 CUs.
+    // A tile's arithmetic does not depend on who runs it: identical bits for every QS.
+    const int QS = gridDim.z;
+    for (int qt = wave * QS + (int)blockIdx.z; qt < nq; qt += NW * QS) {
         const int q = qt * 32 + qi;
         const bf16* qp = base + (int64_t)min(q, Tq - 1) * ld + hi * 8;
         constexpr int NKS = DH / 16;
@@ -249,8 +264,20 @@ int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, 
     static SetokDeviceOnce once;                   // one per instantiation; per device inside
     if (!once.run([] { return hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
         return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
-    attn_vit_kernel<NW, false, DH><<<dim3(H, n_imgs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
-                                                                      0, nullptr, 0, 0);
+    // few (image, head) pairs: split the query tiles of a pair over QS workgroups so that the launch reaches ~2 workgroups per CU (SETOK_ATTN_QSPLIT=n forces n)
+    const int nq = (T + 31) >> 5;
+    int qs = 1;
+    {
+        const char* e = getenv("SETOK_ATTN_QSPLIT");            // (read per call: tests compare the forms in one process)
+        const int forced = e ? atoi(e) : 0;
+        const int pairs = H * n_imgs, slots = 2 * cu_count();
+        if (forced > 0) qs = forced;
+        else if (pairs * 4 <= slots) qs = slots / pairs;
+        if (qs > nq) qs = nq;
+        if (qs < 1) qs = 1;
+    }
+    attn_vit_kernel<NW, false, DH><<<dim3(H, n_imgs, qs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
+                                                                          0, nullptr, 0, 0);
     SETOK_CHECK_LAUNCH("setok_attention(vit bf16)");
     return SETOK_OK;
 }

@@ -694,3 +694,26 @@ def test_cluster_strips_refuse_a_grid_that_cannot_hold_one_image():
             ops.cluster_dpc_knn(xs, B, N, 64, 0.125, 64)
     finally:
         del os.environ["SETOK_STRIP_GRID"]
+
+
+@pytest.mark.parametrize("T,B", [(257, 1), (257, 3), (577, 1), (64, 2)])
+def test_vit_attention_query_split_keeps_its_bits(T, B):
+    """Round 4, small batches: a handful of (image, head) pairs cannot occupy the chip, so the query tiles of a pair are split over several
+    workgroups (each stages the head's K / V).  A tile's arithmetic does not depend on who runs it: every split gives the same bits."""
+    H, Dh = 16, 64
+    g = torch.Generator().manual_seed(T + B)
+    qkv = torch.randn(B * T, 3 * H * Dh, generator=g).bfloat16().to(DEV)
+    outs = []
+    assert os.environ.get("SETOK_ATTN_QSPLIT") is None
+    auto = ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T)
+    for qs in (1, 2, 5, 64):
+        os.environ["SETOK_ATTN_QSPLIT"] = str(qs)
+        try:
+            outs.append(ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T))
+        finally:
+            del os.environ["SETOK_ATTN_QSPLIT"]
+    for o in outs:
+        assert torch.equal(o, auto)
+    q, k, v = (t.reshape(B, T, H, Dh).transpose(1, 2) for t in qkv.float().cpu().split(H * Dh, dim=1))       # and they are the right bits
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * Dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, H * Dh)
+    assert _rel_err(auto.float().cpu(), ref) < 2e-2
