@@ -705,6 +705,9 @@ static TailShape tail_shape_for(int M, int N, int ncu) {
     if (off) return {64, 64, TNS};
     const int t64 = cdiv(M, TT) * cdiv(N, 64);
     if (t64 * 4 <= ncu && N % 32 == 0) return {32, 32, TNS};          // a quarter of the chip: four times the workgroups
+#ifndef SETOK_NO_TWO_PER_CU_3232
+    if (N % 32 == 0 && cdiv(M, 32) * cdiv(N, 32) <= 2 * ncu) return {32, 32, TNS};   // round 4: up to TWO 32 x 32 workgroups per CU (66.5 KiB of LDS each) in one round
+#endif
     if (t64 * 2 <= ncu && N % 32 == 0) return {64, 32, TNS};          // half the chip: twice the workgroups
     if (t64 > ncu && t64 <= 2 * ncu) return {64, 64, 4};              // between one and two rounds: two workgroups per CU, ONE round
     return {64, 64, TNS};
