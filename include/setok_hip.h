@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 5
+#define SETOK_ABI_VERSION 6
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -131,11 +131,16 @@ int setok_activation(void* stream, int dtype, const void* x, void* y, int64_t n,
 
 /* Training-mode dropout of the head's Block: nn.Dropout(proj_drop) after the attention projection (module.py:59,72), after the Mlp's activation
  * and after its fc2 (module.py:36,44,45); proj_drop = 0.2 by default (tokenizer.py:26).
- *   y[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0),   keep_i = hash(seed, offset + i) >= p * 2^32     (residual may be NULL; y may alias x or residual)
- * The mask is a pure function of (seed, offset + i) (a SplitMix64 finaliser over the counter): the backward pass applies the same call to the
+ *   y[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0),   c = offset + i,  keep_i = 16-bit slice (c & 3) of hash(seed, c >> 2) >= p * 2^16
+ *   (residual may be NULL; y may alias x or residual; operands 16-byte aligned)
+ * The mask is a pure function of (seed, offset + i) (one SplitMix64 finaliser per four consecutive counters): the backward pass applies the same call to the
  * incoming gradient instead of storing masks, and a step is reproducible from its seed.  Bernoulli(1 - p) like the reference's masks, not
  * bit-equal to torch's Philox stream.  n elements of `dtype`. */
 int setok_dropout(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint64_t offset);
+/* y = drop(act(x)) in ONE pass: Mlp.forward's `self.drop(self.act(self.fc1(x)))` (module.py:41,44) in training mode.  The same mask as
+ * setok_dropout(seed, offset); act(x) is rounded to `dtype` before the mask is applied, so the result is bit-identical to setok_activation
+ * followed by setok_dropout in place.  ABI 6. */
+int setok_activation_dropout(void* stream, int dtype, const void* x, void* y, int64_t n, int act, float p, uint64_t seed, uint64_t offset);
 
 /* Block-diagonal ("varlen") multi-head self-attention over contiguous row segments.
  * qkv: (rows, 3*H*Dh) laid out [q | k | v], heads inside — the layout both the fused `qkv` Linear
@@ -326,6 +331,9 @@ int setok_layernorm_bwd(void* stream, int dtype, const void* x, const void* dy, 
 
 /* Backward of nn.GELU (exact erf, module.py:41): dx = dy * (Phi(pre) + pre * phi(pre)). */
 int setok_gelu_bwd(void* stream, int dtype, const void* pre, const void* dy, void* dx, int64_t n);
+/* dx = gelu'(pre) * drop(dy): the backward of `drop(act(fc1 x))` in ONE pass — bit-identical to setok_dropout on the gradient (in place) followed by
+ * setok_gelu_bwd.  ABI 6. */
+int setok_gelu_bwd_dropout(void* stream, int dtype, const void* pre, const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset);
 
 /* Backward of setok_attention (module.py:61-73) over the same segments: dqkv laid out [dq | dk | dv] like qkv.
  * out / dout: (rows, H*Dh).  ws: fp32[2 * rows * H] (log-sum-exp and do.o per row and head). */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "setok_layernorm": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f],
     "setok_activation": [_vp, _i, _vp, _vp, _i64, _i],
     "setok_dropout": [_vp, _i, _vp, _vp, _vp, _i64, _f, C.c_uint64, C.c_uint64],
+    "setok_activation_dropout": [_vp, _i, _vp, _vp, _i64, _i, _f, C.c_uint64, C.c_uint64],
     "setok_attention": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f],
     "setok_cross_attention": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _i, _i, _f],
     "setok_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
@@ -64,6 +65,7 @@ SIGNATURES = {
     "setok_colsum": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i],
     "setok_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i],
     "setok_gelu_bwd": [_vp, _i, _vp, _vp, _vp, _i64],
+    "setok_gelu_bwd_dropout": [_vp, _i, _vp, _vp, _vp, _i64, _f, C.c_uint64, C.c_uint64],
     "setok_attention_bwd": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "setok_segment_mean_bwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i],
     "setok_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f],

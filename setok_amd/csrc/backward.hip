@@ -196,6 +196,43 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ pre, const T* __restrict__
     }
 }
 
+// dx = gelu'(pre) * drop(dy): the backward of Mlp's `drop(act(fc1 x))` in one pass.  drop(dy) is rounded to `dtype` first, as the two-launch form
+// (setok_dropout on the gradient in place, then setok_gelu_bwd) rounds it: identical bits.
+template <typename T>
+__global__ void gelu_bwd_dropout_kernel(const T* __restrict__ pre, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, float scale, unsigned thresh16,
+                                        unsigned long long seed, unsigned long long offset) {
+    constexpr int V = Elem<T>::VEC;
+    const int64_t nvec = n / V;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = v * V;
+        float pv[V], gv[V], ov[V];
+        ld_vec<T>(pre + i0, pv);
+        ld_vec<T>(dy + i0, gv);
+        const unsigned long long c0 = offset + (unsigned long long)i0;
+        unsigned long long grp = c0 >> 2, word = dropout_word(seed, grp);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const unsigned long long c = c0 + (unsigned long long)e;
+            if ((c >> 2) != grp) { grp = c >> 2; word = dropout_word(seed, grp); }
+            const bool keep = (unsigned)((word >> (16 * (unsigned)(c & 3))) & 0xffffu) >= thresh16;
+            const float g = (float)(T)(keep ? gv[e] * scale : 0.f);
+            const float x = pv[e];
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            ov[e] = g * (cdf + x * pdf);
+        }
+        st_vec<T>(dx + i0, ov);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nvec * V)) {
+        const int64_t i = nvec * V + threadIdx.x;
+        const float g = (float)(T)(dropout_keep(seed, offset + (unsigned long long)i, thresh16) ? Elem<T>::ld(dy + i) * scale : 0.f);
+        const float x = Elem<T>::ld(pre + i);
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        Elem<T>::st(dx + i, g * (cdf + x * pdf));
+    }
+}
+
 // ---- varlen attention backward, generic (any head dim up to 64 * VEC * 2) ------------------------------------------------------------
 // Forward: s_ij = scale q_i.k_j, p_ij = softmax_j, o_i = sum_j p_ij v_j.  With D_i = do_i.o_i:
 //   ds_ij = p_ij (do_i.v_j - D_i),  dq_i = scale sum_j ds_ij k_j,  dk_j = scale sum_i ds_ij q_i,  dv_j = sum_i p_ij do_i.
@@ -436,6 +473,23 @@ extern "C" int setok_layernorm_bwd(void* stream, int dtype, const void* x, const
     colsum_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(pg, nb, C, dgamma, accumulate);
     colsum_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(pb, nb, C, dbeta, accumulate);
     SETOK_CHECK_LAUNCH("setok_layernorm_bwd");
+    return SETOK_OK;
+}
+
+extern "C" int setok_gelu_bwd_dropout(void* stream, int dtype, const void* pre, const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset) {
+    SETOK_CHECK_ARG(pre && dy && dx && n >= 0, "setok_gelu_bwd_dropout: bad operand");
+    SETOK_CHECK_ARG(p >= 0.f && p < 1.f, "setok_gelu_bwd_dropout: p=%g outside [0, 1)", (double)p);
+    SETOK_CHECK_ARG((((size_t)pre | (size_t)dy | (size_t)dx) & 15) == 0, "setok_gelu_bwd_dropout: operands must be 16-byte aligned");
+    if (n == 0) return SETOK_OK;
+    const int64_t nv = n / (dtype == SETOK_BF16 ? 8 : 4) + 1;
+    const int grid = (int)((nv + 255) / 256 < 65536 ? (nv + 255) / 256 : 65536);
+    const double t = (double)p * 65536.0;
+    const unsigned thresh16 = t >= 65535.0 ? 65535u : (unsigned)(t + 0.5);
+    const float scale = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T("setok_gelu_bwd_dropout", (gelu_bwd_dropout_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)pre, (const bf16*)dy, (bf16*)dx, n, scale, thresh16, seed, offset)),
+               (gelu_bwd_dropout_kernel<float><<<grid, 256, 0, s>>>((const float*)pre, (const float*)dy, (float*)dx, n, scale, thresh16, seed, offset)));
+    SETOK_CHECK_LAUNCH("setok_gelu_bwd_dropout");
     return SETOK_OK;
 }
 

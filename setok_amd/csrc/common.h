@@ -164,6 +164,19 @@ __device__ inline float gelu_erf_fast(float x) {
     return x * (x >= 0.f ? 1.0f - half_tail : half_tail);
 }
 
+// ---- the counter-based dropout mask (glue.hip: setok_dropout explains it): one SplitMix64 finaliser per four consecutive counters ----------
+__device__ inline unsigned long long dropout_word(unsigned long long seed, unsigned long long group) {
+    unsigned long long z = seed + group * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ inline bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned thresh16) {
+    return (unsigned)((dropout_word(seed, ctr >> 2) >> (16 * (unsigned)(ctr & 3))) & 0xffffu) >= thresh16;
+}
+
+
 // ---- LayerNorm folded into the consuming GEMM: the rank-2 start of the accumulators as two-way bf16 splits (gemm_persist.hip) ----------
 __device__ inline void split2(float x, bf16& hi, bf16& lo) {           // x = hi + lo + O(2^-16 |x|), both by truncation
     const unsigned u = __builtin_bit_cast(unsigned, x);

@@ -218,37 +218,103 @@ extern "C" int setok_activation(void* stream, int dtype, const void* x, void* y,
 
 // ---- training-mode dropout of the head's Block (module.py:36,44,45,59,72: nn.Dropout(proj_drop) after the attention projection, after the Mlp's
 // activation and after its fc2; proj_drop = 0.2 by default, tokenizer.py:26) -------------------------------------------------------------------
-// out[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0),  keep_i = hash(seed, offset + i) >= p * 2^32.
-// Counter-based: the mask of element i is a pure function of (seed, offset + i) — the backward pass regenerates it instead of storing it
-// (d/dx = the same mask and scale on the incoming gradient), and a step is reproducible from its seed.  The generator is a SplitMix64
-// finaliser over the counter, not torch's Philox stream: masks are Bernoulli(1 - p) like the reference's, not bit-equal to them.
-__device__ inline bool dropout_keep(unsigned long long seed, unsigned long long ctr, unsigned thresh) {
-    unsigned long long z = seed + ctr * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 32) >= thresh;
+// out[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0).
+// Counter-based: the mask of element i is a pure function of (seed, c = offset + i) — the backward pass regenerates it instead of storing it
+// (d/dx = the same mask and scale on the incoming gradient), and a step is reproducible from its seed.  Round 4: ONE SplitMix64 finaliser per
+// FOUR consecutive counters (word = hash(seed, c >> 2); keep_c = 16-bit slice (c & 3) of the word >= p * 2^16) instead of one per element — the
+// 64-bit multiplies of a hash per element made the kernel compute-bound at 40 % of its memory roofline (2.2 ms of a 70 ms cfg4 step).  p is
+// quantised to 2^-16 (0.2 -> 0.19999695).  Not torch's Philox stream: masks are Bernoulli(1 - p) like the reference's, not bit-equal to them.
+template <typename T>
+__global__ void dropout_kernel(const T* x, const T* res, T* y, int64_t n, float scale, unsigned thresh16, unsigned long long seed, unsigned long long offset) {
+    constexpr int V = Elem<T>::VEC;                                      // 16 bytes per thread and step
+    const int64_t nvec = n / V;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = v * V;
+        float xv[V], rv[V], ov[V];
+        ld_vec<T>(x + i0, xv);
+        if (res) ld_vec<T>(res + i0, rv);
+        const unsigned long long c0 = offset + (unsigned long long)i0;
+        unsigned long long grp = c0 >> 2, word = dropout_word(seed, grp);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const unsigned long long c = c0 + (unsigned long long)e;
+            if ((c >> 2) != grp) { grp = c >> 2; word = dropout_word(seed, grp); }
+            const bool keep = (unsigned)((word >> (16 * (unsigned)(c & 3))) & 0xffffu) >= thresh16;
+            const float d = keep ? xv[e] * scale : 0.f;
+            ov[e] = res ? rv[e] + d : d;
+        }
+        st_vec<T>(y + i0, ov);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nvec * V)) {          // the last n mod V elements
+        const int64_t i = nvec * V + threadIdx.x;
+        const float d = dropout_keep(seed, offset + (unsigned long long)i, thresh16) ? Elem<T>::ld(x + i) * scale : 0.f;
+        Elem<T>::st(y + i, res ? Elem<T>::ld(res + i) + d : d);
+    }
 }
 
+// y = drop(act(x)) in one pass — Mlp.forward's `drop(act(fc1(x)))` (module.py:41,44) in training mode; the intermediate act(x) is rounded to `dtype`
+// first, exactly as the two-launch form (setok_activation, then setok_dropout in place) rounds it: identical bits, one pass over the hidden less.
 template <typename T>
-__global__ void dropout_kernel(const T* x, const T* res, T* y, int64_t n, float scale, unsigned thresh, unsigned long long seed, unsigned long long offset) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = dropout_keep(seed, offset + (unsigned long long)i, thresh) ? Elem<T>::ld(x + i) * scale : 0.f;
-        Elem<T>::st(y + i, res ? Elem<T>::ld(res + i) + v : v);
+__global__ void activation_dropout_kernel(const T* x, T* y, int64_t n, int act, float scale, unsigned thresh16, unsigned long long seed, unsigned long long offset) {
+    constexpr int V = Elem<T>::VEC;
+    const int64_t nvec = n / V;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = v * V;
+        float xv[V], ov[V];
+        ld_vec<T>(x + i0, xv);
+        const unsigned long long c0 = offset + (unsigned long long)i0;
+        unsigned long long grp = c0 >> 2, word = dropout_word(seed, grp);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const unsigned long long c = c0 + (unsigned long long)e;
+            if ((c >> 2) != grp) { grp = c >> 2; word = dropout_word(seed, grp); }
+            const bool keep = (unsigned)((word >> (16 * (unsigned)(c & 3))) & 0xffffu) >= thresh16;
+            const float a = (float)(T)act_apply(xv[e], act);                   // rounded like the stored activation of the two-launch form
+            ov[e] = keep ? a * scale : 0.f;
+        }
+        st_vec<T>(y + i0, ov);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nvec * V)) {
+        const int64_t i = nvec * V + threadIdx.x;
+        const float a = (float)(T)act_apply(Elem<T>::ld(x + i), act);
+        Elem<T>::st(y + i, dropout_keep(seed, offset + (unsigned long long)i, thresh16) ? a * scale : 0.f);
+    }
+}
+
+static inline unsigned dropout_thresh16(float p) {
+    const double t = (double)p * 65536.0;
+    return t >= 65535.0 ? 65535u : (unsigned)(t + 0.5);
+}
+
+extern "C" int setok_activation_dropout(void* stream, int dtype, const void* x, void* y, int64_t n, int act, float p, uint64_t seed, uint64_t offset) {
+    SETOK_CHECK_ARG(x && y && n >= 0, "setok_activation_dropout: bad operand");
+    SETOK_CHECK_ARG(act >= SETOK_ACT_NONE && act <= SETOK_ACT_GELU_ERF, "setok_activation_dropout: bad act %d", act);
+    SETOK_CHECK_ARG(p >= 0.f && p < 1.f, "setok_activation_dropout: p=%g outside [0, 1)", (double)p);
+    SETOK_CHECK_ARG((((size_t)x | (size_t)y) & 15) == 0, "setok_activation_dropout: operands must be 16-byte aligned");
+    if (n == 0) return SETOK_OK;
+    const int64_t nv = n / (dtype == SETOK_BF16 ? 8 : 4) + 1;
+    const int grid = (int)((nv + 255) / 256 < 65536 ? (nv + 255) / 256 : 65536);
+    const float scale = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SETOK_BF16) activation_dropout_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, (bf16*)y, n, act, scale, dropout_thresh16(p), seed, offset);
+    else if (dtype == SETOK_F32) activation_dropout_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, n, act, scale, dropout_thresh16(p), seed, offset);
+    else return setok_fail(SETOK_EINVAL, "setok_activation_dropout: bad dtype %d", dtype);
+    SETOK_CHECK_LAUNCH("setok_activation_dropout");
+    return SETOK_OK;
 }
 
 extern "C" int setok_dropout(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint64_t offset) {
     SETOK_CHECK_ARG(x && y && n >= 0, "setok_dropout: bad operand");
     SETOK_CHECK_ARG(p >= 0.f && p < 1.f, "setok_dropout: p=%g outside [0, 1)", (double)p);
+    SETOK_CHECK_ARG((((size_t)x | (size_t)y | (size_t)residual) & 15) == 0, "setok_dropout: operands must be 16-byte aligned");
     if (n == 0) return SETOK_OK;
-    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
-    const double t = (double)p * 4294967296.0;
-    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    const int64_t nv = n / (dtype == SETOK_BF16 ? 8 : 4) + 1;
+    const int grid = (int)((nv + 255) / 256 < 65536 ? (nv + 255) / 256 : 65536);
+    const unsigned thresh16 = dropout_thresh16(p);
     const float scale = 1.0f / (1.0f - p);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SETOK_BF16) dropout_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, (const bf16*)residual, (bf16*)y, n, scale, thresh, seed, offset);
-    else if (dtype == SETOK_F32) dropout_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)residual, (float*)y, n, scale, thresh, seed, offset);
+    if (dtype == SETOK_BF16) dropout_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, (const bf16*)residual, (bf16*)y, n, scale, thresh16, seed, offset);
+    else if (dtype == SETOK_F32) dropout_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)residual, (float*)y, n, scale, thresh16, seed, offset);
     else return setok_fail(SETOK_EINVAL, "setok_dropout: bad dtype %d", dtype);
     SETOK_CHECK_LAUNCH("setok_dropout");
     return SETOK_OK;

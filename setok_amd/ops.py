@@ -262,6 +262,15 @@ def activation(x: Tensor, act: int, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def activation_dropout(x: Tensor, act: int, p: float, seed: int, offset: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """dropout(activation(x)) in one pass (bit-identical to the two calls)."""
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("setok_activation_dropout", _stream(), _code(x.dtype), _p(x), _p(out), x.numel(), act, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+              int(offset) & 0xFFFFFFFFFFFFFFFF)
+    return out
+
+
 def dropout(x: Tensor, p: float, seed: int, offset: int = 0, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """out = residual + x * mask / (1 - p), mask_i a pure function of (seed, offset + i) (include/setok_hip.h: setok_dropout).  Applying the same
     call (no residual) to an incoming gradient is the backward pass."""
@@ -431,6 +440,14 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float, dgamma: Tens
 def gelu_bwd(pre: Tensor, dy: Tensor) -> Tensor:
     dx = torch.empty_like(pre)
     _lib.call("setok_gelu_bwd", _stream(), _code(pre.dtype), _p(pre), _p(dy), _p(dx), pre.numel())
+    return dx
+
+
+def gelu_bwd_dropout(pre: Tensor, dy: Tensor, p: float, seed: int, offset: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """gelu'(pre) * dropout(dy) in one pass (bit-identical to dropout(dy) then gelu_bwd); `out` may be `dy`."""
+    dx = torch.empty_like(pre) if out is None else out
+    _lib.call("setok_gelu_bwd_dropout", _stream(), _code(pre.dtype), _p(pre), _p(dy), _p(dx), pre.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+              int(offset) & 0xFFFFFFFFFFFFFFFF)
     return dx
 
 

@@ -15,6 +15,8 @@ Every GEMM (forward, dX = dY W, dW = dY^T X) is a `setok_linear` call; the rest 
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -58,6 +60,7 @@ def linear_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, grads: Dict[s
 # ----------------------------------------------------------------------------------------------------------------------------
 # Block (module.py:76-100): `depth` attention sub-layers sharing ONE norm1, then norm2 + Mlp
 # ----------------------------------------------------------------------------------------------------------------------------
+_FUSED_DROPOUT = os.environ.get("SETOK_TRAIN_FUSED_DROPOUT", "1") != "0"     # A/B switch: the two-launch forms of the Mlp's middle dropout (identical bits)
 SITE_STRIDE = 1 << 40          # elements a dropout site may hold: every site draws from its own range of the counter
 
 
@@ -90,11 +93,15 @@ def block_forward_train(blk: Block, x: torch.Tensor, seg_offsets: torch.Tensor, 
             x = ops.dropout(pr, drop.p, drop.seed, drop.offset(i), residual=x, out=pr)
     y2 = ops.layernorm(x, *pk["n2"], pk["eps"])
     pre = ops.linear(y2, pk["w1"], pk["b1"])
-    u = ops.activation(pre, ops.ACT_GELU_ERF)                     # separate from the GEMM here: the backward pass needs `pre`
     if drop is None:
+        u = ops.activation(pre, ops.ACT_GELU_ERF)                 # separate from the GEMM here: the backward pass needs `pre`
         out = ops.linear(u, pk["w2"], pk["b2"], residual=x)
     else:                                                            # x + drop(fc2(drop(act(fc1)))))  (module.py:40-45,98)
-        u = ops.dropout(u, drop.p, drop.seed, drop.offset(depth), out=u)
+        if _FUSED_DROPOUT:
+            u = ops.activation_dropout(pre, ops.ACT_GELU_ERF, drop.p, drop.seed, drop.offset(depth))  # one pass (round 4): = dropout(activation(pre))
+        else:
+            u = ops.activation(pre, ops.ACT_GELU_ERF)
+            u = ops.dropout(u, drop.p, drop.seed, drop.offset(depth), out=u)
         f = ops.linear(u, pk["w2"], pk["b2"])
         out = ops.dropout(f, drop.p, drop.seed, drop.offset(depth + 1), residual=x, out=f)
     ctx.update(xd=x, y2=y2, pre=pre, u=u)                        # u: what fc2 read (after its dropout)
@@ -114,8 +121,12 @@ def block_backward(blk: Block, prefix: str, ctx, g: torch.Tensor, grads: Dict[st
     gf = g if drop is None else ops.dropout(g, drop.p, drop.seed, drop.offset(depth + 1))
     du = linear_bwd(ctx["u"], pk["w2"], gf, grads, prefix + "mlp.fc2", alloc=alloc)
     if drop is not None:
-        du = ops.dropout(du, drop.p, drop.seed, drop.offset(depth), out=du)
-    dpre = ops.gelu_bwd(ctx["pre"], du)
+        if _FUSED_DROPOUT:
+            dpre = ops.gelu_bwd_dropout(ctx["pre"], du, drop.p, drop.seed, drop.offset(depth), out=du)   # one pass (round 4): = gelu_bwd(pre, dropout(du))
+        else:
+            dpre = ops.gelu_bwd(ctx["pre"], ops.dropout(du, drop.p, drop.seed, drop.offset(depth), out=du))
+    else:
+        dpre = ops.gelu_bwd(ctx["pre"], du)
     dy2 = linear_bwd(ctx["y2"], pk["w1"], dpre, grads, prefix + "mlp.fc1", alloc=alloc)
     if alloc:
         g2w, g2b = alloc(prefix + "norm2.weight", (C,)), alloc(prefix + "norm2.bias", (C,))

@@ -227,6 +227,21 @@ def test_dropout_op_is_a_seeded_bernoulli_mask(dt):
         ops.dropout(x, 1.0, seed=1)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_dropout_passes_equal_the_two_launch_forms(dt):
+    """Round 4: drop(act(x)) and gelu'(pre) * drop(dy) as ONE pass each (the Mlp's middle dropout, module.py:41,44): the intermediate is rounded to
+    the storage type exactly as the two-launch forms round it — identical bits, at aligned and unaligned counter offsets, with a ragged tail."""
+    for n, off in ((1 << 18, 0), ((1 << 16) + 5, 7), (13, 1 << 40)):
+        x = (_rand(n, seed=5) * 2.0).to(dt).to(DEV)
+        g = _rand(n, seed=6).to(dt).to(DEV)
+        ref = ops.dropout(ops.activation(x, ops.ACT_GELU_ERF), 0.2, seed=9, offset=off)
+        assert torch.equal(ops.activation_dropout(x, ops.ACT_GELU_ERF, 0.2, seed=9, offset=off), ref)
+        ref_b = ops.gelu_bwd(x, ops.dropout(g, 0.2, seed=9, offset=off))
+        assert torch.equal(ops.gelu_bwd_dropout(x, g, 0.2, seed=9, offset=off), ref_b)
+        g2 = g.clone()
+        assert ops.gelu_bwd_dropout(x, g2, 0.2, seed=9, offset=off, out=g2) is g2 and torch.equal(g2, ref_b)       # in place over the gradient
+
+
 def _block_with_masks(sd, prefix, x, bounds, nheads, depth, masks):
     """Block.forward in TRAINING mode on packed rows (segments = `bounds`), torch autograd, the dropout masks given: masks[i] multiplies the
     attention projection of layer i, masks[depth] the Mlp activation, masks[depth + 1] the fc2 output (module.py:40-45,71-72,96-98)."""
