@@ -1307,7 +1307,9 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
         // (a CPX partition reports its own 32); a CU mask on the stream or the process (hipExtStreamCreateWithCUMask, ROC_GLOBAL_CU_MASK) cuts it down.
         int ncu = 256, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        if (!capturing) {                                                 // (a stream query is not something to issue under capture; a captured graph runs unmasked)
             uint32_t mask[32] = {0};
             if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
                 int bits = 0;
