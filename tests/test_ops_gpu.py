@@ -717,3 +717,30 @@ def test_vit_attention_query_split_keeps_its_bits(T, B):
     q, k, v = (t.reshape(B, T, H, Dh).transpose(1, 2) for t in qkv.float().cpu().split(H * Dh, dim=1))       # and they are the right bits
     ref = (torch.softmax(q @ k.transpose(-1, -2) * Dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, H * Dh)
     assert _rel_err(auto.float().cpu(), ref) < 2e-2
+
+
+def test_cluster_strips_on_a_cu_masked_stream():
+    """ADVICE r03, the real thing: a stream created with a 32-CU mask (hipExtStreamCreateWithCUMask) admits 32 co-resident workgroups of the
+    persistent strip kernel, whatever hipDeviceAttributeMultiprocessorCount says.  The launch must read the mask (hipExtStreamGetCUMask), size its grid
+    and its queue count by it, complete, and give the bits of the unmasked launch."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    B, N, Cc = 24, 576, 256
+    g = torch.Generator().manual_seed(6)
+    cent = torch.randn(30, Cc, generator=g) * 1.5
+    xs = (cent[torch.randint(0, 30, (B, N), generator=g)] + 0.2 * torch.randn(B, N, Cc, generator=g)).bfloat16().to(DEV)
+    full = ops.cluster_dpc_knn(xs.reshape(-1, Cc), B, N, 64, 0.125, 64)
+    torch.cuda.synchronize()
+    mask = (C.c_uint32 * 8)(0xFFFFFFFF, 0, 0, 0, 0, 0, 0, 0)                 # 32 of the 256 CUs
+    st = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask)
+    if rc != 0:
+        pytest.skip(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    try:
+        ext = torch.cuda.ExternalStream(st.value)
+        with torch.cuda.stream(ext):
+            small = ops.cluster_dpc_knn(xs.reshape(-1, Cc), B, N, 64, 0.125, 64)
+        ext.synchronize()
+    finally:
+        hip.hipStreamDestroy(st)
+    assert all(torch.equal(u, v) for u, v in zip(full, small))
