@@ -48,7 +48,11 @@ __device__ inline bf16x8 pack8(const float* p) {
 // the image's cluster tokens (module.py:283-286), the additive -10000 mask of the padded reference realised as a segment.
 // DH = 64 or 48 (the decoder's 768 / 16 heads): 48 runs three QK^T k-steps instead of four and stores 48 of the 64 output
 // columns of the two PV tiles (the LDS slots past the head hold a copy of the head's first chunk: they only reach the unstored columns).
-template <int NW, bool CROSS, int DH>
+// HP (experiment, round 4): heads per workgroup.  HP = 2: a workgroup takes a PAIR of adjacent heads of an image — both heads' K / V
+// staged (2 x the LDS: one workgroup per CU at T = 257), a wave loads its query tile for both heads up front (a row piece of 256 contiguous
+// bytes) and runs the two heads one after the other.  Same arithmetic per (head, query tile): identical bits.  Measured slower; kept behind
+// SETOK_ATTN_HEADPAIR=1 as the evidence (docs/PERF_NOTES.md E.5).
+template <int NW, bool CROSS, int DH, int HP = 1>
 __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                            int T, int H, float scale_log2e, int64_t ldq,
                                                            const bf16* __restrict__ kptr, const bf16* __restrict__ vptr,
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With 8 | images all heads of one image are put on ONE XCD
     // (image b on XCD b % 8): a 48-dim head is 96 bytes of a q|k|v row, so neighbouring heads share 128-byte lines, and lines
     // fetched by one XCD's L2 are not visible to another's.
-    int h = blockIdx.x, b = blockIdx.y;
+    int h = blockIdx.x * HP, b = blockIdx.y;
     if ((gridDim.y & 7) == 0 && DH != 64) {
         const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, k = id >> 3;
         b = xcd + 8 * (k / (int)gridDim.x);
@@ -69,8 +73,6 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
     int kv0 = 0;
     if constexpr (CROSS) { kv0 = kv_offsets[b]; T = min(kv_offsets[b + 1] - kv0, T); }     // T: this image's key count (<= the bound passed in)
     const int Tp = (T + 31) & ~31;
-    char* Ks = lds;
-    char* Vs = lds + (size_t)Tp * ROWB;
     const int Tq = CROSS ? Tq_ : T;
     const int64_t ld = CROSS ? ldq : 3LL * C;                       // query row stride
     const int64_t ldk = CROSS ? ldkv : 3LL * C;                     // key / value row stride
@@ -104,24 +106,30 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(off), "s"(sb64), "s"(dst) : "memory");
         };
+#pragma unroll
+        for (int hh = 0; hh < HP; ++hh) {
+        const bf16* kbase_h = kbase + hh * DH;
+        const bf16* vbase_h = vbase + hh * DH;
+        const unsigned ldsh = lds0 + (unsigned)hh * 2u * (unsigned)Tp * ROWB;
         for (int p0 = wave_u * 64; p0 < npieces; p0 += NW * 64) {    // this wave's 64 consecutive pieces
             const int key0 = p0 >> 3;
             if (ATTN_STAGE_SBASE && key0 + 8 <= T) {                  // (uniform) all eight rows exist
                 const size_t rbytes = (size_t)key0 * (size_t)(ldk * 2);
-                dma_s(reinterpret_cast<const char*>(kbase) + rbytes, koff, lds0 + p0 * 16);
-                dma_s(reinterpret_cast<const char*>(vbase) + rbytes, voff, lds0 + Tp * ROWB + p0 * 16);
+                dma_s(reinterpret_cast<const char*>(kbase_h) + rbytes, koff, ldsh + p0 * 16);
+                dma_s(reinterpret_cast<const char*>(vbase_h) + rbytes, voff, ldsh + Tp * ROWB + p0 * 16);
                 continue;
             }
             const int p = p0 + lane, key = p >> 3, c = p & 7;
             const int64_t roff = (int64_t)min(key, T - 1) * ldk;
             const int kc = c ^ (key & 7);                               // physical slot c of row `key` holds logical chunk c ^ (key & 7)
-            const bf16* ksrc = kbase + roff + ((kc < DH / 8 ? kc : 0) << 3);   // chunks past the head are never read back: fetch something valid
-            const bf16* vsrc = vbase + roff + ((c < DH / 8 ? c : 0) << 3);
+            const bf16* ksrc = kbase_h + roff + ((kc < DH / 8 ? kc : 0) << 3);   // chunks past the head are never read back: fetch something valid
+            const bf16* vsrc = vbase_h + roff + ((c < DH / 8 ? c : 0) << 3);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(ksrc), "s"(lds0 + p0 * 16) : "memory");
+                         : "=&s"(keep) : "v"(ksrc), "s"(ldsh + p0 * 16) : "memory");
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(vsrc), "s"(lds0 + Tp * ROWB + p0 * 16) : "memory");
+                         : "=&s"(keep) : "v"(vsrc), "s"(ldsh + Tp * ROWB + p0 * 16) : "memory");
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -146,9 +154,17 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
         const int q = qt * 32 + qi;
         const bf16* qp = base + (int64_t)min(q, Tq - 1) * ld + hi * 8;
         constexpr int NKS = DH / 16;
-        bf16x8 qf[NKS];
+        bf16x8 qfh[HP][NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        for (int hh = 0; hh < HP; ++hh)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qfh[hh][ks] = *reinterpret_cast<const bf16x8*>(qp + hh * DH + ks * 16);
+#pragma unroll
+        for (int hh = 0; hh < HP; ++hh) {
+        const bf16x8 (&qf)[NKS] = qfh[hh];
+        const char* Ks = lds + (size_t)hh * 2 * Tp * ROWB;
+        const char* Vs = Ks + (size_t)Tp * ROWB;
+        const int hcur = h + hh;
 
         f32x16 o[2];
 #pragma unroll
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
                     cw[j][w] = r[0]; cw[j + 4][w] = r[1];
                 }
             if (q < Tq) {
-                bf16* op = out + ((int64_t)b * Tq + q) * (int64_t)C + h * DH + hi * 32;
+                bf16* op = out + ((int64_t)b * Tq + q) * (int64_t)C + hcur * DH + hi * 32;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint4 piece = {cw[j][0], cw[j][1], cw[j + 4][0], cw[j + 4][1]};
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
                 }
             }
         } else if (q < Tq) {
-            bf16* op = out + ((int64_t)b * Tq + q) * (CROSS ? ldo : (int64_t)C) + h * DH;
+            bf16* op = out + ((int64_t)b * Tq + q) * (CROSS ? ldo : (int64_t)C) + hcur * DH;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
                     *reinterpret_cast<bf16x4*>(op + d * 32 + 8 * r4 + 4 * hi) = v;   // dims (r&3) + 8*(r>>2) + 4*hi
                 }
         }
+        }                                                            // hh
     }
 }
 
@@ -275,6 +292,18 @@ int launch(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, 
         else if (pairs * 4 <= slots) qs = slots / pairs;
         if (qs > nq) qs = nq;
         if (qs < 1) qs = 1;
+    }
+    if constexpr (DH == 64 && NW == 8) {                             // experiment: a workgroup per (image, PAIR of heads)
+        const char* hp = getenv("SETOK_ATTN_HEADPAIR");
+        if (hp && hp[0] == '1' && H % 2 == 0 && 2 * smem <= 160 * 1024) {
+            static SetokDeviceOnce once2;
+            if (!once2.run([] { return hipFuncSetAttribute((const void*)attn_vit_kernel<NW, false, DH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
+                return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
+            attn_vit_kernel<NW, false, DH, 2><<<dim3(H / 2, n_imgs, qs), NW * 64, 2 * smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
+                                                                                         0, nullptr, 0, 0);
+            SETOK_CHECK_LAUNCH("setok_attention(vit bf16, head pairs)");
+            return SETOK_OK;
+        }
     }
     attn_vit_kernel<NW, false, DH><<<dim3(H, n_imgs, qs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f, 0, nullptr, nullptr,
                                                                           0, nullptr, 0, 0);

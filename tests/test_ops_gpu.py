@@ -714,6 +714,11 @@ def test_vit_attention_query_split_keeps_its_bits(T, B):
             del os.environ["SETOK_ATTN_QSPLIT"]
     for o in outs:
         assert torch.equal(o, auto)
+    os.environ["SETOK_ATTN_HEADPAIR"] = "1"                                # the head-pair experiment (a workgroup per pair of adjacent heads): same bits
+    try:
+        assert torch.equal(ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T), auto)
+    finally:
+        del os.environ["SETOK_ATTN_HEADPAIR"]
     q, k, v = (t.reshape(B, T, H, Dh).transpose(1, 2) for t in qkv.float().cpu().split(H * Dh, dim=1))       # and they are the right bits
     ref = (torch.softmax(q @ k.transpose(-1, -2) * Dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, H * Dh)
     assert _rel_err(auto.float().cpu(), ref) < 2e-2
