@@ -132,7 +132,7 @@ int setok_activation(void* stream, int dtype, const void* x, void* y, int64_t n,
 /* Training-mode dropout of the head's Block: nn.Dropout(proj_drop) after the attention projection (module.py:59,72), after the Mlp's activation
  * and after its fc2 (module.py:36,44,45); proj_drop = 0.2 by default (tokenizer.py:26).
  *   y[i] = residual[i] + (keep_i ? x[i] / (1 - p) : 0),   c = offset + i,  keep_i = 16-bit slice (c & 3) of hash(seed, c >> 2) >= p * 2^16
- *   (residual may be NULL; y may alias x or residual; operands 16-byte aligned)
+ *   (residual may be NULL; y may alias x or residual; 16-byte aligned operands take the vector kernel, others an element-wise one: same mask)
  * The mask is a pure function of (seed, offset + i) (one SplitMix64 finaliser per four consecutive counters): the backward pass applies the same call to the
  * incoming gradient instead of storing masks, and a step is reproducible from its seed.  Bernoulli(1 - p) like the reference's masks, not
  * bit-equal to torch's Philox stream.  n elements of `dtype`. */

@@ -303,11 +303,28 @@ extern "C" int setok_activation_dropout(void* stream, int dtype, const void* x, 
     return SETOK_OK;
 }
 
+template <typename T>
+__global__ void dropout_scalar_kernel(const T* x, const T* res, T* y, int64_t n, float scale, unsigned thresh16, unsigned long long seed, unsigned long long offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {      // operands not 16-byte aligned (a view)
+        const float d = dropout_keep(seed, offset + (unsigned long long)i, thresh16) ? Elem<T>::ld(x + i) * scale : 0.f;
+        Elem<T>::st(y + i, res ? Elem<T>::ld(res + i) + d : d);
+    }
+}
+
 extern "C" int setok_dropout(void* stream, int dtype, const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, uint64_t offset) {
     SETOK_CHECK_ARG(x && y && n >= 0, "setok_dropout: bad operand");
     SETOK_CHECK_ARG(p >= 0.f && p < 1.f, "setok_dropout: p=%g outside [0, 1)", (double)p);
-    SETOK_CHECK_ARG((((size_t)x | (size_t)y | (size_t)residual) & 15) == 0, "setok_dropout: operands must be 16-byte aligned");
     if (n == 0) return SETOK_OK;
+    if ((((size_t)x | (size_t)y | (size_t)residual) & 15) != 0) {         // same mask, element by element
+        const int g1 = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+        hipStream_t s1 = (hipStream_t)stream;
+        const float sc = 1.0f / (1.0f - p);
+        if (dtype == SETOK_BF16) dropout_scalar_kernel<bf16><<<g1, 256, 0, s1>>>((const bf16*)x, (const bf16*)residual, (bf16*)y, n, sc, dropout_thresh16(p), seed, offset);
+        else if (dtype == SETOK_F32) dropout_scalar_kernel<float><<<g1, 256, 0, s1>>>((const float*)x, (const float*)residual, (float*)y, n, sc, dropout_thresh16(p), seed, offset);
+        else return setok_fail(SETOK_EINVAL, "setok_dropout: bad dtype %d", dtype);
+        SETOK_CHECK_LAUNCH("setok_dropout");
+        return SETOK_OK;
+    }
     const int64_t nv = n / (dtype == SETOK_BF16 ? 8 : 4) + 1;
     const int grid = (int)((nv + 255) / 256 < 65536 ? (nv + 255) / 256 : 65536);
     const unsigned thresh16 = dropout_thresh16(p);

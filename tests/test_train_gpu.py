@@ -222,6 +222,8 @@ def test_dropout_op_is_a_seeded_bernoulli_mask(dt):
     x2 = x.clone()
     assert ops.dropout(x2, p, seed=77, offset=5, out=x2) is x2 and torch.equal(x2, y)
     assert torch.equal(ops.dropout(x, 0.0, seed=1), x)
+    xo = x[3:]                                                                                   # a view that is not 16-byte aligned: the element-wise kernel, the same mask
+    assert torch.equal(ops.dropout(xo, p, seed=77, offset=8), y[3:])
     from setok_amd._lib import SetokHipError
     with pytest.raises(SetokHipError):
         ops.dropout(x, 1.0, seed=1)
