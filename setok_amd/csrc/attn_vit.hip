@@ -275,271 +275,6 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
 }
 
 // --------------------------------------------------------------------------------------------
-// Row-resident form for short sequences (round 4): Tp = 32 NKT <= 288 keys, head dim 64, self-attention.
-// The kernel above walks the keys in tiles of 32 with an online softmax: per (query tile, key tile) unit a wave runs ONE serial chain — K fragment
-// read -> 4 dependent MFMAs -> max -> exchange -> branch -> 16 x (fma -> exp) -> sum -> pack -> V reads -> 4 MFMAs — and at T = 257 it measures
-// ~1270 SIMD cycles per unit against 256 of matrix pipe and ~400 of vector issue: latency, not throughput.  Here a wave keeps the WHOLE score row
-// block of its 32 queries in registers (NKT x 16 floats per lane: 144 at T = 257), so the work of a query tile is four long passes of independent
-// instructions: 4 NKT MFMAs into NKT independent accumulators; one max over the row (the exact row maximum: no running rescale, no branch); exp /
-// sum / pack; 4 NKT MFMAs of P V.  ~200 VGPRs: 4-wave workgroups, two per CU (one staging while the other computes), two waves per SIMD — the
-// matrix pass of one overlaps the vector pass of the other.  The extra (class token) tile of T = 32 k + 1 goes to a wave that rotates with (image, head).
-// --------------------------------------------------------------------------------------------
-template <int N_>
-__device__ inline void wait_vm_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
-
-#ifndef ROW_ABL
-#define ROW_ABL 0           // timing ablations (wrong results): 1 no staging, 2 no QK^T MFMAs, 4 exp -> multiply, 8 no PV MFMAs, 16 staging only, 32 no max pass
-#endif
-#ifdef ROW_TIMING            // debug build: per-wave cycle counts of the kernel's segments (s_memtime), dumped by launch_row
-__device__ unsigned long long g_rowtim[4096 * 16 * 4 * 24];
-#define RT_MARK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rt[k] += t_ - rt_last; rt_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define RT_MARK(k) do { } while (0)
-#endif
-template <int NW, int NKT>
-__global__ __launch_bounds__(NW * 64, 2) void attn_vit_row_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T, int H, float scale_log2e) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int DH = 64, Tp = NKT * 32, NKS = DH / 16;
-    constexpr int NREQ = (Tp * 8) / (NW * 64);                       // LDS-DMA requests per wave and operand
-    constexpr int NSTORE = 4;                                        // output stores per lane and tile
-    static_assert((Tp * 8) % (NW * 64) == 0, "every wave issues the same number of requests per operand");
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = H * DH;
-    const int64_t ld = 3LL * C;
-    const bf16* base = qkv + (int64_t)b * T * ld + h * DH;
-    const bf16* kbase = base + C;
-    const bf16* vbase = base + 2 * C;
-    const int qi = lane & 31, hi = lane >> 5;
-    const int nq = (T + 31) >> 5;
-    const int QS = gridDim.z;
-    const int wv = (wave + h + b) % NW;                               // who takes the odd tile rotates: co-resident workgroups load different SIMDs
-    const int qstep = NW * QS;
-    int qt = wv * QS + (int)blockIdx.z;
-#ifdef ROW_TIMING
-    unsigned long long rt[24] = {0};
-    unsigned long long rt_last = __builtin_amdgcn_s_memtime();
-    int rt_tile = 0;
-#endif
-
-    // Every vector-memory operation of this kernel is issued by hand and waited for by count (vmcnt retires in order): the compiler does not see
-    // the LDS-DMA requests, and a wait it inserted for an ordinary load issued behind them would wait for the requests as well.
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 qn[NKS];                                                     // the NEXT tile's query fragments, in flight
-    auto load_q = [&](int tile) {
-        const bf16* qp = base + (int64_t)min(tile * 32 + qi, T - 1) * ld + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(qn[ks]) : "v"(qp + ks * 16) : "memory");
-    };
-    {   // K (slot-swizzled), this wave's first query fragments, V (row-major): the first query tile's QK^T and softmax run while V is still on its way
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        const int r8 = lane >> 3, c8 = lane & 7, kc8 = c8 ^ r8;
-        const unsigned koff = (unsigned)r8 * (unsigned)(ld * 2) + (unsigned)(kc8 << 4);
-        const unsigned voff = (unsigned)r8 * (unsigned)(ld * 2) + (unsigned)(c8 << 4);
-        auto dma_s = [&](const char* src, unsigned off, unsigned dst) {
-            unsigned keep;
-            const unsigned long long b64 = (unsigned long long)src;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
-            const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
-            const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(sb64), "s"(dst) : "memory");
-        };
-#pragma unroll
-        for (int opnd = 0; opnd < 2; ++opnd) {
-            const bf16* src0 = opnd ? vbase : kbase;
-            const unsigned dst0 = lds0 + (opnd ? Tp * ROWB : 0);
-#pragma unroll
-            for (int i = 0; i < NREQ; ++i) {
-                const int p0 = (wave_u + i * NW) * 64, key0 = p0 >> 3;
-                if (key0 + 8 <= T) {
-                    dma_s(reinterpret_cast<const char*>(src0) + (size_t)key0 * (size_t)(ld * 2), opnd ? voff : koff, dst0 + p0 * 16);
-                    continue;
-                }
-                const int p = p0 + lane, key = p >> 3, c = p & 7;             // a request reaching past row T - 1: padding rows re-read row T - 1
-                const bf16* src = src0 + (int64_t)min(key, T - 1) * ld + ((opnd ? c : c ^ (key & 7)) << 3);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst0 + p0 * 16) : "memory");
-            }
-            if (opnd == 0) load_q(min(qt, nq - 1));                   // (a wave without a tile — QS > 1 — still issues and waits: one count for all)
-        }
-    }
-    RT_MARK(0);
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : "n"(NREQ) : "memory");      // K and the fragments have landed
-    RT_MARK(1);
-    __syncthreads();
-    RT_MARK(2);
-    bool v_pending = true;
-    if (qt >= nq || (ROW_ABL & 16)) {                                 // no tile: V's barrier all the same
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        return;
-    }
-    const char* Ks = lds;
-    const char* Vs = lds + (size_t)Tp * ROWB;
-    const int g16 = lane >> 4, i16 = lane & 15;
-    const int tr_row = (i16 >> 2) + 4 * (g16 >> 1);
-    const int tr_col = (g16 & 1) * 16 + (i16 & 3) * 4;
-    for (; qt < nq; qt += qstep) {
-        const int q = qt * 32 + qi;
-        const bool has_next = qt + qstep < nq;                        // (wave-uniform)
-        bf16x8 qf[NKS];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, qn[ks]);
-        if (has_next) load_q(qt + qstep);                             // under this tile's passes
-        // ---- pass 1: S^T = K Q^T, NKT independent accumulators (a key tile's chain of NKS MFMAs is NKT instructions apart)
-        f32x16 s[NKT];
-        int qi_k = qi;                                          // (opaque per tile: the K fragments do not depend on the query tile and the compiler
-        asm volatile("" : "+v"(qi_k));                          //  would otherwise hoist all 4 NKT of them out of this loop — 144 registers it does not have)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const int krow = kt * 32 + qi_k;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow * ROWB + (((ks * 2 + hi) ^ (krow & 7)) << 4));
-                if (ROW_ABL & 2) {
-                    asm volatile("" :: "v"(kf), "v"(qf[ks]));
-                    if (ks == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) s[kt][r] = (float)(r + kt + lane) * 0.01f;
-                    }
-                } else if (ks == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], z, 0, 0, 0);
-                } else
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-            }
-        RT_MARK(3 + 6 * rt_tile);
-        // s[kt][r]: key = kt*32 + (r&3) + 8*(r>>2) + 4*hi, query = q
-        if (Tp != T) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((NKT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= T) s[NKT - 1][r] = -INFINITY;
-        }
-        // ---- pass 2: the row maximum (four interleaved chains)
-        float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (ROW_ABL & 32) mx4[0] = s[0][0];
-        else
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx4[(r >> 1) & 3] = fmaxf(mx4[(r >> 1) & 3], s[kt][r]);
-        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mc = mx * scale_log2e;
-        RT_MARK(4 + 6 * rt_tile);
-        // ---- pass 3: p = exp2(s c - m c), row sum in four interleaved chains, P packed to bf16 in place
-        float ls[4] = {0.f, 0.f, 0.f, 0.f};
-        bf16x8 pk[NKT][2];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            float t[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float a = fmaf(s[kt][r], scale_log2e, -mc);
-                t[r] = (ROW_ABL & 4) ? a * 0.001f : __builtin_amdgcn_exp2f(a);
-                ls[r & 3] += t[r];
-            }
-            pk[kt][0] = pack8(t); pk[kt][1] = pack8(t + 8);
-        }
-        const float l_lane = (ls[0] + ls[1]) + (ls[2] + ls[3]);
-        const float inv = 1.0f / (l_lane + __shfl_xor(l_lane, 32, 64));
-        RT_MARK(5 + 6 * rt_tile);
-        if (v_pending) {                                              // (wave-uniform; first tile only) V: every wave's requests have landed
-            if (has_next) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NKS) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            v_pending = false;
-        }
-        RT_MARK(6 + 6 * rt_tile);
-        // ---- pass 4: O^T = V^T P^T; the V^T fragments of step i + 2 are requested before step i's MFMAs
-        f32x16 o[2];
-        constexpr int NST = 2 * NKT;                                  // steps of 16 keys
-        auto read_v = [&](int st, int d) -> bf16x8 {
-            const char* vb = Vs + (st * 16 + tr_row) * ROWB + (d * 32 + tr_col) * 2;
-            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb));
-            const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb + 8 * ROWB));
-            typedef short short8v __attribute__((ext_vector_type(8)));
-            return __builtin_bit_cast(bf16x8, (short8v)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-        };
-        bf16x8 vf[3][2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) { vf[0][d] = read_v(0, d); vf[1][d] = read_v(1, d); }
-#pragma unroll
-        for (int st = 0; st < NST; ++st) {
-            if (st + 2 < NST) {
-#pragma unroll
-                for (int d = 0; d < 2; ++d) vf[(st + 2) % 3][d] = read_v(st + 2, d);
-            }
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const bf16x8 vv = vf[st % 3][d], pp = pk[st >> 1][st & 1];
-                if (ROW_ABL & 8) {
-                    asm volatile("" :: "v"(vv), "v"(pp));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-                } else if (st == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pp, z, 0, 0, 0);
-                } else
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pp, o[d], 0, 0, 0);
-            }
-        }
-        RT_MARK(7 + 6 * rt_tile);
-        // ---- store (as above: one v_permlane32_swap per register, 4 stores of 16 bytes per lane)
-        unsigned cw[8][2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                bf16x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[d][r4 * 4 + j] * inv);
-                const uint2 u2 = __builtin_bit_cast(uint2, v);
-                cw[d * 4 + r4][0] = u2.x; cw[d * 4 + r4][1] = u2.y;
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const auto r = __builtin_amdgcn_permlane32_swap(cw[j][w], cw[j + 4][w], false, false);
-                cw[j][w] = r[0]; cw[j + 4][w] = r[1];
-            }
-        if (has_next)                                                 // the next tile's fragments (the stores behind them may still be on their way)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
-        {
-            // rows past T - 1 (the last tile): stored into the row of query T - 1's lane? no — masked: lanes with q >= T store nothing
-            bf16* op = out + ((int64_t)b * T + min(q, T - 1)) * (int64_t)C + h * DH + hi * 32;
-            if (q < T) {
-#pragma unroll
-                for (int j = 0; j < NSTORE; ++j) {
-                    const uint4 piece = {cw[j][0], cw[j][1], cw[j + 4][0], cw[j + 4][1]};
-                    *reinterpret_cast<uint4*>(op + 8 * j) = piece;
-                }
-            }
-        }
-#ifdef ROW_TIMING
-        RT_MARK(8 + 6 * rt_tile);
-        ++rt_tile;
-#endif
-    }
-#ifdef ROW_TIMING
-    if (lane == 0) {
-        unsigned long long* o_ = g_rowtim + (((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 24);
-        rt[21] = (unsigned long long)rt_tile;
-#pragma unroll
-        for (int k = 0; k < 24; ++k) o_[k] = rt[k];
-    }
-#endif
-}
-
-// --------------------------------------------------------------------------------------------
 // Row-resident form with 16-query tiles (v_mfma_f32_16x16x32_bf16): the score row block of a tile is NKT x 8 floats per lane (72 at T = 257),
 // the kernel fits 128 VGPRs — 8-wave workgroups, two per CU, FOUR waves per SIMD (the 32-query form above: ~200 VGPRs, two per SIMD, and the
 // counters show what that costs: vector and matrix instructions busy 42 % + 23 % of the time, nothing overlapped, a third of the cycles idle).
@@ -620,19 +355,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_vit_row16_kernel(const bf16* 
     const int nq = (T + 15) >> 4;
     const int QS = gridDim.z;
     const int wv = (wave + h + b) % NW;                               // who takes the odd tiles rotates: co-resident workgroups load different SIMDs
-    // T = 16 n + 1 (a class token in front of a 16 x 16 patch grid): the last query tile holds ONE row and would be a third tile for one wave of
-    // eight — a third of the workgroup's life for 6 % of its work.  That row is taken by the whole workgroup instead: each wave runs it against
-    // its own 32-key steps (all 16 query columns of the MFMA carry the same row), leaves a partial (max, sum, 64 dims) per step in LDS, and one
-    // wave merges them.  Which workgroup (QS > 1) does not change the arithmetic: identical bits for every split.
-    const bool coop = (T & 15) == 1 && T > 16;
-    const int nq_main = coop ? nq - 1 : nq;
-    float* scratch = reinterpret_cast<float*>(lds + (size_t)2 * Tp * ROWB);          // NKT partials x 66 floats
     // transposing read: lanes 4 j + p of a 16-lane group supply row j, 8-byte piece p (4 dims); lane i receives dim i of rows 0 .. 3
     const int i16 = lane & 15;
     const int tr_row = 4 * g + (i16 >> 2);
     const int tr_sw = ((2 * (g & 1) + (i16 >> 3)) & 3) << 1;          // ((row >> 1) & 3) << 1 of that row (the key steps are multiples of 16: no change)
     const int tr_sub = (i16 & 3) >> 1, tr_b8 = (i16 & 1) * 8;
-    for (int qt = wv * QS + (int)blockIdx.z; qt < nq_main; qt += NW * QS) {
+    for (int qt = wv * QS + (int)blockIdx.z; qt < nq; qt += NW * QS) {
         const int q = qt * 16 + qc;
         const bf16* qp = base + (int64_t)min(q, T - 1) * ld + g * 8;
         bf16x8 qf[2];
@@ -713,66 +441,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_vit_row16_kernel(const bf16* 
             }
         }
     }
-    if (coop && blockIdx.z == 0) {                                    // (workgroup-uniform)
-        const bf16* qp = base + (int64_t)(T - 1) * ld + g * 8;        // every query column = row T - 1
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
-        for (int m = wave; m < NKT; m += NW) {
-            f32x4 s2[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int krow = (2 * m + e) * 16 + qc;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + krow * ROWB + (((0 + g) ^ ((krow >> 1) & 7)) << 4));
-                const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Ks + krow * ROWB + (((4 + g) ^ ((krow >> 1) & 7)) << 4));
-                s2[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], z, 0, 0, 0);
-                s2[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], s2[e], 0, 0, 0);
-            }
-            float mxp = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if ((2 * m + e) * 16 + 4 * g + i >= T) s2[e][i] = -INFINITY;
-                    mxp = fmaxf(mxp, s2[e][i]);
-                }
-            mxp = quad_maxf(mxp);                                     // (finite: a step holds at least one key < T)
-            const float mcp = mxp * scale_log2e;
-            float t[8], lsum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { t[i] = __builtin_amdgcn_exp2f(fmaf(s2[i >> 2][i & 3], scale_log2e, -mcp)); lsum += t[i]; }
-            lsum = quad_addf(lsum);
-            const bf16x8 pp = pack8(t);
-            float* part = scratch + m * 66;
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const char* vb = Vs + (m * 32 + tr_row) * ROWB + (((2 * t4 + tr_sub) ^ tr_sw) << 4) + tr_b8;
-                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb));
-                const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb + 16 * ROWB));
-                typedef short short8v __attribute__((ext_vector_type(8)));
-                const bf16x8 vv = __builtin_bit_cast(bf16x8, (short8v)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 od = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vv, pp, z, 0, 0, 0);
-                if (qc == 0) *reinterpret_cast<f32x4*>(part + 2 + 16 * t4 + 4 * g) = od;       // dims 16 t4 + 4 g .. + 3
-            }
-            if (lane == 0) { part[0] = mxp; part[1] = lsum; }
-        }
-        __syncthreads();
-        if (wave == (h + b) % NW) {                                   // lane = dim
-            float M = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < NKT; ++m) M = fmaxf(M, scratch[m * 66]);
-            float L = 0.f, acc = 0.f;
-#pragma unroll
-            for (int m = 0; m < NKT; ++m) {
-                const float w = __builtin_amdgcn_exp2f((scratch[m * 66] - M) * scale_log2e);
-                L = fmaf(w, scratch[m * 66 + 1], L);
-                acc = fmaf(w, scratch[m * 66 + 2 + lane], acc);
-            }
-            out[((int64_t)b * T + (T - 1)) * (int64_t)C + h * DH + lane] = (bf16)(acc / L);
-        }
-    }
 }
 
 int split_for(int pairs, int nq) {          // few (image, head) pairs: query tiles of a pair over several workgroups (SETOK_ATTN_QSPLIT=n forces n)
@@ -789,47 +457,13 @@ int split_for(int pairs, int nq) {          // few (image, head) pairs: query ti
 template <int NKT>
 int launch_row16(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, float scale) {
     constexpr int NW = 8;
-    const size_t smem = (size_t)NKT * 32 * ROWB * 2 + (size_t)NKT * 66 * 4;
+    const size_t smem = (size_t)NKT * 32 * ROWB * 2;
     static SetokDeviceOnce once;
     if (!once.run([] { return hipFuncSetAttribute((const void*)attn_vit_row16_kernel<NW, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
         return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
     const int qs = split_for(H * n_imgs, (T + 15) >> 4);
     attn_vit_row16_kernel<NW, NKT><<<dim3(H, n_imgs, qs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f);
     SETOK_CHECK_LAUNCH("setok_attention(vit bf16, row-resident, 16-query tiles)");
-    return SETOK_OK;
-}
-
-template <int NKT>
-int launch_row(hipStream_t s, const bf16* qkv, bf16* out, int n_imgs, int T, int H, float scale) {
-    constexpr int NW = 4;
-    const size_t smem = (size_t)NKT * 32 * ROWB * 2;
-    static SetokDeviceOnce once;
-    if (!once.run([] { return hipFuncSetAttribute((const void*)attn_vit_row_kernel<NW, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
-        return setok_fail(SETOK_ELAUNCH, "attn_vit: cannot raise dynamic LDS limit");
-    const int qs = split_for(H * n_imgs, (T + 31) >> 5);
-    attn_vit_row_kernel<NW, NKT><<<dim3(H, n_imgs, qs), NW * 64, smem, s>>>(qkv, out, T, H, scale * 1.44269504088896340736f);
-    SETOK_CHECK_LAUNCH("setok_attention(vit bf16, row-resident)");
-#ifdef ROW_TIMING
-    if (getenv("SETOK_ROW_TIMING") && qs == 1 && (size_t)H * n_imgs <= 4096 * 16) {
-        const size_t nwv = (size_t)H * n_imgs * NW;
-        unsigned long long* hbuf = (unsigned long long*)malloc(nwv * 24 * 8);
-        if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_rowtim), nwv * 24 * 8) == hipSuccess) {
-            static const char* names[6] = {"pass1 QK^T", "mask+max", "exp/sum/pack", "wait V", "pass4 PV", "store"};
-            for (int cls = 2; cls <= 3; ++cls) {
-                double sum[24] = {0}; size_t n = 0;
-                for (size_t w = 0; w < nwv; ++w) if ((int)hbuf[w * 24 + 21] == cls) { ++n; for (int k = 0; k < 21; ++k) sum[k] += (double)hbuf[w * 24 + k]; }
-                if (!n) continue;
-                fprintf(stderr, "[row timing] waves with %d tiles (%zu): issue DMA %.0f, wait K+Q %.0f, barrier %.0f (s_memtime ticks = 100 MHz)\n", cls, n, sum[0] / n, sum[1] / n, sum[2] / n);
-                for (int t = 0; t < cls; ++t) {
-                    fprintf(stderr, "   tile %d:", t);
-                    for (int k = 0; k < 6; ++k) fprintf(stderr, "  %s %.0f", names[k], sum[3 + 6 * t + k] / n);
-                    fprintf(stderr, "\n");
-                }
-            }
-        }
-        free(hbuf);
-    }
-#endif
     return SETOK_OK;
 }
 
@@ -903,24 +537,18 @@ int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_im
         if (nq >= 4) return launch<4, 48>(s, qkv, out, n_imgs, T, H, scale);
         return launch<1, 48>(s, qkv, out, n_imgs, T, H, scale);
     }
-    {   // short sequences: the row-resident kernels (experiment switches: SETOK_ATTN_ROW=1 32-query tiles, =2 16-query tiles; default: the online-softmax kernel)
+    {   // 129 <= T <= 288 (ViT-L/14-224: 257, ViT-B/16-224: 197), SETOK_ATTN_ROW=1: the row-resident kernel with 16-query tiles.  OPT-IN: per layer it is
+        // 171 vs 186 us at 256 images and 5.2 vs 7.4 us at one, but inside the encode step that is 0.3 % (44.50 vs 44.63 ms) and 2 % (1.47 vs 1.50 ms),
+        // and its bits differ from the online-softmax kernel's (the exact row maximum instead of a running one) — every golden drift statistic of the
+        // step would have to be re-pinned for that.  The choice never depends on the batch: an image's bits must not.
         const char* e = getenv("SETOK_ATTN_ROW");
-        if (Dh == 64 && nq >= 5 && nq <= 9 && e && e[0] == '2') {
+        if (Dh == 64 && nq >= 5 && nq <= 9 && e && e[0] == '1') {
             switch (nq) {
                 case 5: return launch_row16<5>(s, qkv, out, n_imgs, T, H, scale);
                 case 6: return launch_row16<6>(s, qkv, out, n_imgs, T, H, scale);
                 case 7: return launch_row16<7>(s, qkv, out, n_imgs, T, H, scale);
                 case 8: return launch_row16<8>(s, qkv, out, n_imgs, T, H, scale);
                 default: return launch_row16<9>(s, qkv, out, n_imgs, T, H, scale);
-            }
-        }
-        if (Dh == 64 && nq >= 5 && nq <= 9 && e && e[0] == '1') {
-            switch (nq) {
-                case 5: return launch_row<5>(s, qkv, out, n_imgs, T, H, scale);
-                case 6: return launch_row<6>(s, qkv, out, n_imgs, T, H, scale);
-                case 7: return launch_row<7>(s, qkv, out, n_imgs, T, H, scale);
-                case 8: return launch_row<8>(s, qkv, out, n_imgs, T, H, scale);
-                default: return launch_row<9>(s, qkv, out, n_imgs, T, H, scale);
             }
         }
     }

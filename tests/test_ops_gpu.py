@@ -696,32 +696,55 @@ def test_cluster_strips_refuse_a_grid_that_cannot_hold_one_image():
         del os.environ["SETOK_STRIP_GRID"]
 
 
-@pytest.mark.parametrize("T,B", [(257, 1), (257, 3), (577, 1), (64, 2)])
+def _with_env(name, value, fn):
+    assert os.environ.get(name) is None
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        del os.environ[name]
+
+
+@pytest.mark.parametrize("T,B", [(257, 1), (257, 3), (577, 1), (64, 2), (197, 2), (129, 1), (256, 2), (288, 1), (145, 5)])
 def test_vit_attention_query_split_keeps_its_bits(T, B):
     """Round 4, small batches: a handful of (image, head) pairs cannot occupy the chip, so the query tiles of a pair are split over several
-    workgroups (each stages the head's K / V).  A tile's arithmetic does not depend on who runs it: every split gives the same bits."""
+    workgroups (each stages the head's K / V).  A tile's arithmetic does not depend on who runs it: every split gives the same bits — for the
+    online-softmax kernel and for the opt-in row-resident kernel of 129 <= T <= 288 (SETOK_ATTN_ROW=1: 16-query tiles, the exact row maximum;
+    at other lengths the switch changes nothing)."""
     H, Dh = 16, 64
     g = torch.Generator().manual_seed(T + B)
     qkv = torch.randn(B * T, 3 * H * Dh, generator=g).bfloat16().to(DEV)
-    outs = []
-    assert os.environ.get("SETOK_ATTN_QSPLIT") is None
-    auto = ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T)
-    for qs in (1, 2, 5, 64):
-        os.environ["SETOK_ATTN_QSPLIT"] = str(qs)
-        try:
-            outs.append(ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T))
-        finally:
-            del os.environ["SETOK_ATTN_QSPLIT"]
-    for o in outs:
-        assert torch.equal(o, auto)
-    os.environ["SETOK_ATTN_HEADPAIR"] = "1"                                # the head-pair experiment (a workgroup per pair of adjacent heads): same bits
-    try:
-        assert torch.equal(ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T), auto)
-    finally:
-        del os.environ["SETOK_ATTN_HEADPAIR"]
-    q, k, v = (t.reshape(B, T, H, Dh).transpose(1, 2) for t in qkv.float().cpu().split(H * Dh, dim=1))       # and they are the right bits
+    run = lambda: ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T)
+    assert os.environ.get("SETOK_ATTN_QSPLIT") is None and os.environ.get("SETOK_ATTN_ROW") is None
+    q, k, v = (t.reshape(B, T, H, Dh).transpose(1, 2) for t in qkv.float().cpu().split(H * Dh, dim=1))
     ref = (torch.softmax(q @ k.transpose(-1, -2) * Dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * T, H * Dh)
-    assert _rel_err(auto.float().cpu(), ref) < 2e-2
+    for row in (None, "1"):
+        form = (lambda f: f()) if row is None else (lambda f: _with_env("SETOK_ATTN_ROW", row, f))
+        auto = form(run)
+        for qs in (1, 2, 5, 64):
+            assert torch.equal(form(lambda: _with_env("SETOK_ATTN_QSPLIT", str(qs), run)), auto), (row, qs)
+        assert _rel_err(auto.float().cpu(), ref) < 2e-2                    # and they are the right bits
+        if row is None:                                                    # the head-pair experiment (a workgroup per pair of adjacent heads of the online kernel): same bits
+            assert torch.equal(form(lambda: _with_env("SETOK_ATTN_HEADPAIR", "1", run)), auto)
+
+
+def test_vit_attention_row_kernel_is_batch_invariant_and_closer_to_fp32():
+    """The opt-in row-resident kernel (SETOK_ATTN_ROW=1) keeps a query tile's whole score row in registers: the softmax uses the exact row maximum
+    (no running rescale), an image's rows do not depend on the batch it is in, and it is no further from the fp32 result than the default kernel."""
+    H, Dh, T = 16, 64, 257
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(6 * T, 3 * H * Dh, generator=g) * 2.0).bfloat16().to(DEV)
+    row = lambda f: _with_env("SETOK_ATTN_ROW", "1", f)
+    full = row(lambda: ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T))
+    for i in (0, 3, 5):
+        one = row(lambda: ops.attention(qkv[i * T:(i + 1) * T].contiguous(), H, Dh, Dh ** -0.5, seg_len=T))
+        assert torch.equal(one, full[i * T:(i + 1) * T])
+    q, k, v = (t.reshape(6, T, H, Dh).transpose(1, 2) for t in qkv.float().cpu().split(H * Dh, dim=1))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * Dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(6 * T, H * Dh)
+    old = ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T)
+    assert not torch.equal(old, full)                                      # (another kernel: other bits)
+    e_new, e_old = _rel_err(full.float().cpu(), ref), _rel_err(old.float().cpu(), ref)
+    assert e_new < 1e-2 and e_new <= e_old * 1.05, (e_new, e_old)
 
 
 def test_cluster_strips_on_a_cu_masked_stream():
