@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 6
+#define SETOK_ABI_VERSION 7
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -362,6 +362,9 @@ int setok_rmsnorm(void* stream, int dtype, const void* x, const float* weight, v
 /* apply_rotary_pos_emb (rotate_half convention, default rope: inv_freq = theta^(-2i/Dh), cos / sin in fp32 rounded to dtype) in
  * place on the q and k thirds of qkv: (rows, 3*H*Dh) laid out [q | k | v]; position_ids: int64[rows]. */
 int setok_rope(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Dh, float theta);
+/* ... with grouped-query attention (LlamaConfig.num_key_value_heads = Hkv < H, H % Hkv == 0: Llama-2-70B, Llama-3, Mistral): rows of
+ * (H + 2*Hkv)*Dh elements [q: H heads | k: Hkv heads | v: Hkv heads]; the H + Hkv heads of q and k are rotated.  Hkv == H is setok_rope. */
+int setok_rope_gqa(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Hkv, int Dh, float theta);
 
 /* LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) on a fused (rows, 2*F) buffer [gate | up] -> (rows, F); act_fn = SiLU. */
 int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_t rows, int F);
@@ -373,6 +376,10 @@ int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_
  * mix; they are padding and masked out of the loss, setokim_llama.py:149-152). */
 int setok_attention_causal(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Dh,
                            float scale);
+/* ... with grouped-query attention (HF repeat_kv, modeling_llama.py: query head h reads key / value head h / (H / Hkv)): qkv rows of
+ * (H + 2*Hkv)*Dh elements [q | k | v], out rows of H*Dh.  Hkv == H is setok_attention_causal (same kernels, same bits). */
+int setok_attention_causal_gqa(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Hkv, int Dh,
+                               float scale);
 
 /* The language-model loss of SetokimLlamaForCausalLM.forward (setokim_llama.py:145-160): logits (B*T rows of V, row stride ld) are read as
  * fp32; position t predicts labels[t + 1]; positions with attention_mask[t + 1] == 0 (NULL = none) or labels[t + 1] == ignore_index are left

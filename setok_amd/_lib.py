@@ -71,8 +71,10 @@ SIGNATURES = {
     "setok_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f],
     "setok_rmsnorm": [_vp, _i, _vp, _vp, _vp, _i, _i, _f],
     "setok_rope": [_vp, _i, _vp, _vp, _i, _i, _i, _f],
+    "setok_rope_gqa": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f],
     "setok_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
     "setok_attention_causal": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f],
+    "setok_attention_causal_gqa": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f],
     "setok_lm_loss": [_vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "setok_splice_rows": [_vp, _i, _vp, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp],
     "setok_splice_rows_bwd": [_vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i],

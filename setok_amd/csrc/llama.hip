@@ -69,9 +69,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const T* __restrict__
 
 // ---- rotary embedding on q and k of [q | k | v] rows -----------------------------------------------------------------------------------------
 // One thread per (row, chunk of V dims of the first half): cos / sin of its V angles are computed ONCE and reused for the row's 2H heads
-// (the angle depends on the position and the dim only), every head costs two 16-byte loads and two 16-byte stores.
+// (the angle depends on the position and the dim only), every head costs two 16-byte loads and two 16-byte stores.  Grouped-query attention:
+// H query heads, Hkv <= H key heads, rows of (H + 2 Hkv) Dh elements.
 template <typename T>
-__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Dh, float log2_theta) {
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Hkv, int Dh, float log2_theta) {
     constexpr int V = Elem<T>::VEC;
     const int half = Dh >> 1, chunks = half / V;
     const int64_t total = (int64_t)rows * chunks;
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const in
             const float ang = p * (1.0f / exp2f(log2_theta * (float)(2 * (ch * V + e)) / (float)Dh));
             c[e] = rnd<T>(cosf(ang)); s[e] = rnd<T>(sinf(ang));
         }
-        T* base = qkv + r * (int64_t)(3 * H * Dh) + ch * V;
-        for (int hh = 0; hh < 2 * H; ++hh) {                              // q heads, then k heads: contiguous in [q | k | v]
+        T* base = qkv + r * (int64_t)((H + 2 * Hkv) * Dh) + ch * V;
+        for (int hh = 0; hh < H + Hkv; ++hh) {                            // q heads, then k heads: contiguous in [q | k | v]
             T* q = base + (int64_t)hh * Dh;
             float x1[V], x2[V], o1[V], o2[V];
             ld_vec<T>(q, x1); ld_vec<T>(q + half, x2);
@@ -102,16 +103,17 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const in
 
 // scalar fallback for head dims whose half is not a multiple of the vector width
 template <typename T>
-__global__ void rope_scalar_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Dh, float log2_theta) {
+__global__ void rope_scalar_kernel(T* __restrict__ qkv, const int64_t* __restrict__ pos, int rows, int H, int Hkv, int Dh, float log2_theta) {
     const int half = Dh >> 1;
-    const int64_t total = (int64_t)rows * 2 * H * half;
+    const int HR = H + Hkv;
+    const int64_t total = (int64_t)rows * HR * half;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % half);
-        const int hh = (int)((i / half) % (2 * H));
-        const int64_t r = i / ((int64_t)half * 2 * H);
+        const int hh = (int)((i / half) % HR);
+        const int64_t r = i / ((int64_t)half * HR);
         const float ang = (float)pos[r] * (1.0f / exp2f(log2_theta * (float)(2 * d) / (float)Dh));
         const float c = rnd<T>(cosf(ang)), s = rnd<T>(sinf(ang));
-        T* p = qkv + r * (int64_t)(3 * H * Dh) + (int64_t)hh * Dh + d;
+        T* p = qkv + r * (int64_t)((H + 2 * Hkv) * Dh) + (int64_t)hh * Dh + d;
         const float x1 = (float)p[0], x2 = (float)p[half];
         p[0] = (T)(rnd<T>(x1 * c) + rnd<T>(-x2 * s));
         p[half] = (T)(rnd<T>(x2 * c) + rnd<T>(x1 * s));
@@ -137,18 +139,20 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T
 // ---- generic causal attention: one wave per (query row, head) ------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void attn_causal_generic_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ kmask, T* __restrict__ out,
-                                                                 int Tn, int H, int Dh, float scale) {
+                                                                 int Tn, int H, int Hkv, int Dh, float scale) {
     extern __shared__ float ps[];                                      // Tn scores
     const int row = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int b = row / Tn, i = row % Tn;
-    const int64_t C = (int64_t)H * Dh, ld = 3 * C;
+    const int64_t C = (int64_t)H * Dh, ld = (int64_t)(H + 2 * Hkv) * Dh;
+    const int hk = h / (H / Hkv);                                      // grouped-query attention: H / Hkv query heads share a key / value head (repeat_kv)
+    const int64_t KO = C + (int64_t)hk * Dh - (int64_t)h * Dh, VO = C + (int64_t)Hkv * Dh + (int64_t)hk * Dh - (int64_t)h * Dh;   // from `base` to the key / value head
     const T* base = qkv + (int64_t)b * Tn * ld + h * Dh;
     float mx = -INFINITY;
     for (int j = lane; j <= i; j += 64) {
         float acc = -INFINITY;
         if (!kmask || kmask[(int64_t)b * Tn + j]) {
             acc = 0.f;
-            for (int d = 0; d < Dh; ++d) acc = fmaf((float)base[(int64_t)i * ld + d], (float)base[(int64_t)j * ld + C + d], acc);
+            for (int d = 0; d < Dh; ++d) acc = fmaf((float)base[(int64_t)i * ld + d], (float)base[(int64_t)j * ld + KO + d], acc);
             acc *= scale;
         }
         ps[j] = acc;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64) void attn_causal_generic_kernel(const T* __rest
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     for (int d = lane; d < Dh; d += 64) {
         float o = 0.f;
-        for (int j = 0; j <= i; ++j) o = fmaf(rnd<T>(ps[j] * inv), (float)base[(int64_t)j * ld + 2 * C + d], o);   // probabilities cast to dtype (HF)
+        for (int j = 0; j <= i; ++j) o = fmaf(rnd<T>(ps[j] * inv), (float)base[(int64_t)j * ld + VO + d], o);   // probabilities cast to dtype (HF)
         out[((int64_t)b * Tn + i) * C + h * Dh + d] = (T)o;
     }
 }
@@ -181,7 +185,7 @@ __device__ inline bf16x8 pack8c(const float* p) {
 }
 
 __global__ __launch_bounds__(256) void attn_causal_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ kmask, bf16* __restrict__ out,
-                                                          int Tn, int H, float scale_log2e) {
+                                                          int Tn, int H, int Hkv, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char Ks[2][32 * CROW];       // K tile, 16-byte slots XOR-swizzled by (row & 15)
     __shared__ __attribute__((aligned(16))) char Vs[2][32 * CROW];       // V tile, row-major (hardware-transposing reads)
     const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;                 // heavy (late) query blocks first: the causal triangle
@@ -189,8 +193,10 @@ __global__ __launch_bounds__(256) void attn_causal_kernel(const bf16* __restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = lane & 31, hi = lane >> 5;
-    const int64_t C = (int64_t)H * CD, ld = 3 * C;
+    const int64_t C = (int64_t)H * CD, ld = (int64_t)(H + 2 * Hkv) * CD;
     const bf16* base = qkv + (int64_t)b * Tn * ld + h * CD;
+    const int hk = h / (H / Hkv);                                        // grouped-query attention: the key / value head of this query head
+    const int64_t KO = C + (int64_t)(hk - h) * CD, VO = C + (int64_t)Hkv * CD + (int64_t)(hk - h) * CD;
     const uint8_t* km = kmask ? kmask + (int64_t)b * Tn : nullptr;
     const int q0 = qb * CQ + wave * 32;                                  // this wave's first query
     const int q = q0 + qi;
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(256) void attn_causal_kernel(const bf16* __restrict
         for (int i = 0; i < 2; ++i) {
             const int p = i * 256 + tid, row = p >> 4, c = p & 15;
             const bf16* src = base + (int64_t)min(kt * 32 + row, Tn - 1) * ld;
-            const bf16* ksrc = src + C + ((c ^ (row & 15)) << 3);        // physical slot c of a row holds logical chunk c ^ (row & 15)
-            const bf16* vsrc = src + 2 * C + (c << 3);
+            const bf16* ksrc = src + KO + ((c ^ (row & 15)) << 3);       // physical slot c of a row holds logical chunk c ^ (row & 15)
+            const bf16* vsrc = src + VO + (c << 3);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(ksrc), "s"(klds + buf * (32 * CROW) + i * 4096) : "memory");
@@ -410,9 +416,9 @@ extern "C" int setok_rmsnorm(void* stream, int dtype, const void* x, const float
     return SETOK_OK;
 }
 
-extern "C" int setok_rope(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Dh, float theta) {
+extern "C" int setok_rope_gqa(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Hkv, int Dh, float theta) {
     SETOK_CHECK_ARG(qkv && position_ids, "setok_rope: null operand");
-    SETOK_CHECK_ARG(rows >= 0 && H > 0 && Dh > 0 && Dh % 2 == 0 && theta > 0.f, "setok_rope: bad shape");
+    SETOK_CHECK_ARG(rows >= 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Dh > 0 && Dh % 2 == 0 && theta > 0.f, "setok_rope: bad shape (H=%d Hkv=%d Dh=%d)", H, Hkv, Dh);
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     const float l2 = log2f(theta);
@@ -420,16 +426,20 @@ extern "C" int setok_rope(void* stream, int dtype, void* qkv, const int64_t* pos
     if ((Dh / 2) % V == 0) {
         const int64_t total = (int64_t)rows * (Dh / 2 / V);
         const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-        LL_DISPATCH("setok_rope", (rope_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Dh, l2)),
-                    (rope_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Dh, l2)));
+        LL_DISPATCH("setok_rope", (rope_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Hkv, Dh, l2)),
+                    (rope_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Hkv, Dh, l2)));
     } else {
-        const int64_t total = (int64_t)rows * H * Dh;
+        const int64_t total = (int64_t)rows * (H + Hkv) * (Dh / 2);
         const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-        LL_DISPATCH("setok_rope", (rope_scalar_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Dh, l2)),
-                    (rope_scalar_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Dh, l2)));
+        LL_DISPATCH("setok_rope", (rope_scalar_kernel<bf16><<<grid, 256, 0, s>>>((bf16*)qkv, position_ids, rows, H, Hkv, Dh, l2)),
+                    (rope_scalar_kernel<float><<<grid, 256, 0, s>>>((float*)qkv, position_ids, rows, H, Hkv, Dh, l2)));
     }
     SETOK_CHECK_LAUNCH("setok_rope");
     return SETOK_OK;
+}
+
+extern "C" int setok_rope(void* stream, int dtype, void* qkv, const int64_t* position_ids, int rows, int H, int Dh, float theta) {
+    return setok_rope_gqa(stream, dtype, qkv, position_ids, rows, H, H, Dh, theta);
 }
 
 extern "C" int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_t rows, int F) {
@@ -444,14 +454,15 @@ extern "C" int setok_swiglu(void* stream, int dtype, const void* gate_up, void* 
     return SETOK_OK;
 }
 
-extern "C" int setok_attention_causal(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Dh,
-                                      float scale) {
+extern "C" int setok_attention_causal_gqa(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Hkv,
+                                          int Dh, float scale) {
     SETOK_CHECK_ARG(qkv && out, "setok_attention_causal: null operand");
-    SETOK_CHECK_ARG(B >= 0 && T > 0 && H > 0 && Dh > 0 && Dh % 8 == 0, "setok_attention_causal: bad shape B=%d T=%d H=%d Dh=%d", B, T, H, Dh);
+    SETOK_CHECK_ARG(B >= 0 && T > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Dh > 0 && Dh % 8 == 0,
+                    "setok_attention_causal: bad shape B=%d T=%d H=%d Hkv=%d Dh=%d", B, T, H, Hkv, Dh);
     if (B == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SETOK_BF16 && Dh == CD) {
-        attn_causal_kernel<<<dim3(cdiv(T, CQ), H, B), 256, 0, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, scale * 1.44269504088896340736f);
+        attn_causal_kernel<<<dim3(cdiv(T, CQ), H, B), 256, 0, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, Hkv, scale * 1.44269504088896340736f);
         SETOK_CHECK_LAUNCH("setok_attention_causal(bf16 mfma)");
         return SETOK_OK;
     }
@@ -459,10 +470,15 @@ extern "C" int setok_attention_causal(void* stream, int dtype, const void* qkv, 
     SETOK_CHECK_ARG(smem <= 64 * 1024, "setok_attention_causal: T=%d too long for the generic kernel", T);
     dim3 grid(B * T, H);
     LL_DISPATCH("setok_attention_causal",
-                (attn_causal_generic_kernel<bf16><<<grid, 64, smem, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, Dh, scale)),
-                (attn_causal_generic_kernel<float><<<grid, 64, smem, s>>>((const float*)qkv, key_mask, (float*)out, T, H, Dh, scale)));
+                (attn_causal_generic_kernel<bf16><<<grid, 64, smem, s>>>((const bf16*)qkv, key_mask, (bf16*)out, T, H, Hkv, Dh, scale)),
+                (attn_causal_generic_kernel<float><<<grid, 64, smem, s>>>((const float*)qkv, key_mask, (float*)out, T, H, Hkv, Dh, scale)));
     SETOK_CHECK_LAUNCH("setok_attention_causal");
     return SETOK_OK;
+}
+
+extern "C" int setok_attention_causal(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Dh,
+                                      float scale) {
+    return setok_attention_causal_gqa(stream, dtype, qkv, key_mask, out, B, T, H, H, Dh, scale);
 }
 
 extern "C" int setok_lm_loss(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels, const uint8_t* attention_mask, int B,

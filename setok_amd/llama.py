@@ -10,8 +10,9 @@
 `model.layers.{i}.{input,post_attention}_layernorm.weight`, `model.norm.weight`, `lm_head.weight`) so a Vicuna / Llama-2 checkpoint loads
 unchanged, and runs the prefill (no KV cache, eager-attention arithmetic) as: RMSNorm -> one fused q|k|v GEMM -> rotary embedding in place
 -> causal + padding-masked MFMA attention -> o_proj GEMM with the residual fused -> RMSNorm -> one fused gate|up GEMM -> SwiGLU ->
-down_proj GEMM with the residual fused.  Inference only; grouped-query attention (num_key_value_heads < num_attention_heads) is not
-implemented on the HIP path (Vicuna-7B / 13B do not use it).
+down_proj GEMM with the residual fused.  Inference only.  Grouped-query attention (num_key_value_heads < num_attention_heads: Llama-2-70B,
+Llama-3, Mistral — Vicuna-7B / 13B do not use it) runs on the same kernels: the fused q|k|v rows are [H | Hkv | Hkv] heads wide and query head h
+reads key / value head h // (H // Hkv), HF's `repeat_kv` without the copies.
 """
 from __future__ import annotations
 
@@ -65,9 +66,10 @@ class LlamaModel(PackCacheMixin, nn.Module):
     def __init__(self, vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, num_key_value_heads, rms_norm_eps,
                  rope_theta):
         super().__init__()
-        if num_key_value_heads != num_attention_heads:
-            raise NotImplementedError("grouped-query attention is not implemented on the HIP path (Vicuna-7B/13B use plain multi-head attention)")
+        if num_key_value_heads < 1 or num_attention_heads % num_key_value_heads != 0:
+            raise ValueError(f"num_attention_heads ({num_attention_heads}) must be a multiple of num_key_value_heads ({num_key_value_heads})")
         self.num_heads, self.head_dim, self.rope_theta, self.eps = num_attention_heads, hidden_size // num_attention_heads, rope_theta, rms_norm_eps
+        self.num_kv_heads = num_key_value_heads
         self.embed_tokens = nn.Embedding(vocab_size, hidden_size)
         self.layers = nn.ModuleList([_DecoderLayer(hidden_size, num_attention_heads, num_key_value_heads, intermediate_size, rms_norm_eps)
                                      for _ in range(num_hidden_layers)])
@@ -102,7 +104,7 @@ class LlamaModel(PackCacheMixin, nn.Module):
     def _forward(self, inputs_embeds, attention_mask=None, position_ids=None):
         B, T, D = inputs_embeds.shape
         pk = self._pack()
-        H, dh = self.num_heads, self.head_dim
+        H, Hkv, dh = self.num_heads, self.num_kv_heads, self.head_dim
         dev = inputs_embeds.device
         x = inputs_embeds.to(self.norm.weight.dtype).reshape(B * T, D).contiguous().clone()
         if position_ids is None:
@@ -113,8 +115,8 @@ class LlamaModel(PackCacheMixin, nn.Module):
         for L in pk["layers"]:
             y = ops.rmsnorm(x, L["n1"], self.eps, out=y)
             qkv = ops.linear(y, L["wqkv"])
-            ops.rope_(qkv, pos, H, dh, self.rope_theta)
-            o = ops.attention_causal(qkv, km, B, T, H, dh, dh ** -0.5)
+            ops.rope_(qkv, pos, H, dh, self.rope_theta, Hkv)
+            o = ops.attention_causal(qkv, km, B, T, H, dh, dh ** -0.5, Hkv)
             ops.linear(o, L["wo"], residual=x, out=x)
             y = ops.rmsnorm(x, L["n2"], self.eps, out=y)
             gu = ops.linear(y, L["wgu"])

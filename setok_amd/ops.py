@@ -488,11 +488,12 @@ def rmsnorm(x: Tensor, weight: Tensor, eps: float, out: Optional[Tensor] = None)
     return out
 
 
-def rope_(qkv: Tensor, position_ids: Tensor, H: int, Dh: int, theta: float) -> Tensor:
-    """In place on the q and k thirds of qkv (rows, 3*H*Dh)."""
+def rope_(qkv: Tensor, position_ids: Tensor, H: int, Dh: int, theta: float, Hkv: Optional[int] = None) -> Tensor:
+    """In place on the q and k parts of qkv (rows, (H + 2*Hkv)*Dh) laid out [q | k | v]; Hkv (grouped-query attention) defaults to H."""
     rows = qkv.shape[0]
-    assert qkv.shape[1] == 3 * H * Dh and position_ids.dtype == torch.int64 and position_ids.numel() == rows
-    _lib.call("setok_rope", _stream(), _code(qkv.dtype), _p(qkv), _p(position_ids.contiguous()), rows, H, Dh, theta)
+    Hkv = H if Hkv is None else Hkv
+    assert qkv.shape[1] == (H + 2 * Hkv) * Dh and position_ids.dtype == torch.int64 and position_ids.numel() == rows
+    _lib.call("setok_rope_gqa", _stream(), _code(qkv.dtype), _p(qkv), _p(position_ids.contiguous()), rows, H, Hkv, Dh, theta)
     return qkv
 
 
@@ -517,10 +518,12 @@ def lm_loss(logits: Tensor, labels: Tensor, attention_mask: Optional[Tensor], ig
     return out
 
 
-def attention_causal(qkv: Tensor, key_mask: Optional[Tensor], B: int, T: int, H: int, Dh: int, scale: float) -> Tensor:
-    assert qkv.shape == (B * T, 3 * H * Dh)
+def attention_causal(qkv: Tensor, key_mask: Optional[Tensor], B: int, T: int, H: int, Dh: int, scale: float, Hkv: Optional[int] = None) -> Tensor:
+    """Causal, key-padding-masked attention over B sequences of T rows [q: H heads | k: Hkv | v: Hkv]; Hkv < H: grouped-query attention."""
+    Hkv = H if Hkv is None else Hkv
+    assert qkv.shape == (B * T, (H + 2 * Hkv) * Dh) and H % Hkv == 0
     if key_mask is not None:
         assert key_mask.dtype == torch.uint8 and key_mask.numel() == B * T
     out = torch.empty((B * T, H * Dh), dtype=qkv.dtype, device=qkv.device)
-    _lib.call("setok_attention_causal", _stream(), _code(qkv.dtype), _p(qkv), _p(key_mask), _p(out), B, T, H, Dh, scale)
+    _lib.call("setok_attention_causal_gqa", _stream(), _code(qkv.dtype), _p(qkv), _p(key_mask), _p(out), B, T, H, Hkv, Dh, scale)
     return out

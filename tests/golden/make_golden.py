@@ -479,6 +479,10 @@ LLAMA_CASES = {
     "tiny_left": (dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=100), 8, 3, 11, "left"),
     "dh128": (dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=128), 9, 2, 150, "right"),
     "dh128_left": (dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=128), 10, 2, 70, "left"),
+    # grouped-query attention (num_key_value_heads < num_attention_heads: HF repeat_kv)
+    "gqa_tiny_left": (dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=100), 11, 3, 13, "left"),
+    "gqa_dh128": (dict(hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=128), 12, 2, 150, "right"),
+    "mqa_dh128_left": (dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=128), 13, 2, 70, "left"),
 }
 
 

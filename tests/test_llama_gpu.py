@@ -87,6 +87,40 @@ def test_attention_causal_with_padding(dt, tol, H, Dh, T):
     assert _rel(nomask, _causal_ref(qkv, torch.ones(B, T), B, T, H, Dh)) < tol
 
 
+def _causal_ref_gqa(qkv, km, B, T, H, Hkv, Dh):
+    """HF repeat_kv: query head h attends with key / value head h // (H // Hkv)."""
+    x = qkv.double().reshape(B, T, (H + 2 * Hkv) * Dh)
+    q = x[..., :H * Dh].reshape(B, T, H, Dh).transpose(1, 2)
+    k = x[..., H * Dh:(H + Hkv) * Dh].reshape(B, T, Hkv, Dh).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    v = x[..., (H + Hkv) * Dh:].reshape(B, T, Hkv, Dh).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    allow = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None] & km.bool().reshape(B, 1, 1, T)
+    s = ((q @ k.transpose(-1, -2)) * Dh ** -0.5).masked_fill(~allow, float("-inf"))
+    return (torch.softmax(s, -1).nan_to_num(0.0) @ v).transpose(1, 2).reshape(B * T, H * Dh)
+
+
+@pytest.mark.parametrize("dt,tol,H,Hkv,Dh,T", [(torch.float32, 3e-6, 6, 2, 16, 37), (torch.bfloat16, 1e-2, 4, 2, 128, 200), (torch.bfloat16, 1e-2, 8, 1, 128, 65),
+                                                (torch.bfloat16, 2e-2, 4, 2, 64, 70)])
+def test_attention_causal_and_rope_grouped_query(dt, tol, H, Hkv, Dh, T):
+    """num_key_value_heads < num_attention_heads (Llama-2-70B / Llama-3 / Mistral): rows are [q: H heads | k: Hkv | v: Hkv]; the kernels index the
+    shared key / value head instead of materialising HF's repeat_kv copies.  With Hkv == H the entry points are the plain ones (same bits)."""
+    B = 2
+    W = (H + 2 * Hkv) * Dh
+    qkv = _rand(B * T, W, seed=16).to(dt)
+    km = torch.ones(B, T, dtype=torch.uint8)
+    km[1, :T // 5] = 0
+    got = ops.attention_causal(qkv.to(DEV), km.reshape(-1).to(DEV), B, T, H, Dh, Dh ** -0.5, Hkv)
+    assert _rel(got, _causal_ref_gqa(qkv, km, B, T, H, Hkv, Dh)) < tol
+    pos = torch.randint(0, 3000, (B * T,), generator=torch.Generator().manual_seed(17))
+    cos, sin = O.llama_rope_tables(pos[None], Dh, 10000.0, dt)
+    qk = qkv[:, :(H + Hkv) * Dh].reshape(B * T, H + Hkv, Dh)
+    ref = (qk * cos[0][:, None]) + (O._rotate_half(qk) * sin[0][:, None])
+    rot = ops.rope_(qkv.to(DEV).clone(), pos.to(DEV), H, Dh, 10000.0, Hkv).cpu()
+    assert _rel(rot[:, :(H + Hkv) * Dh], ref.reshape(B * T, -1).double()) < (4e-5 if dt == torch.float32 else 1e-2)   # (fp32: cos / sin of angles up to 3000 rad)
+    assert torch.equal(rot[:, (H + Hkv) * Dh:], qkv[:, (H + Hkv) * Dh:])        # v untouched
+    full = _rand(B * T, 3 * H * Dh, seed=18).to(dt).to(DEV)                        # Hkv == H: the plain entry points, bit for bit
+    assert torch.equal(ops.attention_causal(full, None, B, T, H, Dh, Dh ** -0.5, H), ops.attention_causal(full, None, B, T, H, Dh, Dh ** -0.5))
+
+
 def _case(golden_dir, name):
     z = np.load(os.path.join(golden_dir, "llama.npz"))
     kw = {str(k): int(v) for k, v in zip(z[name + ":cfg_keys"], z[name + ":cfg_vals"])}
@@ -97,7 +131,7 @@ def _case(golden_dir, name):
     return kw, sd, x, am, pos, _t(z[name + ":hidden"]), _t(z[name + ":logits"])
 
 
-@pytest.mark.parametrize("name", ["tiny_right", "tiny_left", "dh128", "dh128_left"])
+@pytest.mark.parametrize("name", ["tiny_right", "tiny_left", "dh128", "dh128_left", "gqa_tiny_left", "gqa_dh128", "mqa_dh128_left"])
 def test_llama_prefill_fp32_vs_hf(golden_dir, name):
     kw, sd, x, am, pos, hidden, logits = _case(golden_dir, name)
     m = SetokimLlamaPrefill(kw)
@@ -111,7 +145,7 @@ def test_llama_prefill_fp32_vs_hf(golden_dir, name):
     assert _rel(last.cpu(), logits[torch.arange(am.shape[0]), idx]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["dh128", "dh128_left"])
+@pytest.mark.parametrize("name", ["dh128", "dh128_left", "gqa_dh128", "mqa_dh128_left"])
 def test_llama_prefill_bf16_mfma_attention(golden_dir, name):
     kw, sd, x, am, pos, hidden, logits = _case(golden_dir, name)
     m = SetokimLlamaPrefill(kw)

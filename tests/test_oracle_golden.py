@@ -266,7 +266,7 @@ def test_head_param_grads_match_reference_autograd(golden_dir):
 
 
 # ---- §8(f) last row: the LLM prefill of cfg 5 -------------------------------------------------------------------------------
-LLAMA_NAMES = ["tiny_right", "tiny_left", "dh128", "dh128_left"]
+LLAMA_NAMES = ["tiny_right", "tiny_left", "dh128", "dh128_left", "gqa_tiny_left", "gqa_dh128", "mqa_dh128_left"]     # the last three: num_key_value_heads < num_attention_heads
 
 
 def _llama_case(golden_dir, name):
