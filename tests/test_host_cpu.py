@@ -16,8 +16,12 @@ def test_llama_mirror_has_hf_state_dict_keys():
     assert set(a) == set(b)
     assert all(tuple(a[k].shape) == tuple(b[k].shape) for k in a)
     assert set(O.init_llama_weights(O.LlamaConfigLite(**kw))) == set(a)
-    with pytest.raises(NotImplementedError):
-        SetokimLlamaPrefill(dict(kw, num_key_value_heads=2))
+    kw2 = dict(kw, num_key_value_heads=2)                                       # grouped-query attention: k_proj / v_proj of Hkv heads, the same key names
+    hf2 = LlamaForCausalLM(LlamaConfig(**kw2, attention_bias=False, mlp_bias=False, tie_word_embeddings=False)).state_dict()
+    mine2 = SetokimLlamaPrefill(kw2).state_dict()
+    assert set(hf2) == set(mine2) and all(tuple(hf2[k].shape) == tuple(mine2[k].shape) for k in hf2)
+    with pytest.raises(ValueError):
+        SetokimLlamaPrefill(dict(kw, num_key_value_heads=3))                   # 4 query heads cannot share 3 key / value heads
 
 
 def test_detokenizer_mirror_keys_and_ctor_errors():
