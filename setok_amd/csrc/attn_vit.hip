@@ -12,6 +12,11 @@
 //           cross-lane movement at all).
 // HBM traffic per (image, head): read Q, K, V once, write O once — the algorithmic minimum.
 #include "common.h"
+#if defined(ATTN_NT) && (ATTN_NT & 4)     // A/B switch: the K / V staging requests as streaming loads
+#define ATTN_KV_NT " nt"
+#else
+#define ATTN_KV_NT ""
+#endif
 
 namespace {
 
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
             const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
             const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ATTN_KV_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(off), "s"(sb64), "s"(dst) : "memory");
         };
 #pragma unroll
@@ -125,9 +130,9 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             const bf16* ksrc = kbase_h + roff + ((kc < DH / 8 ? kc : 0) << 3);   // chunks past the head are never read back: fetch something valid
             const bf16* vsrc = vbase_h + roff + ((c < DH / 8 ? c : 0) << 3);
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ATTN_KV_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(ksrc), "s"(ldsh + p0 * 16) : "memory");
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ATTN_KV_NT "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(vsrc), "s"(ldsh + Tp * ROWB + p0 * 16) : "memory");
         }
         }
@@ -158,7 +163,13 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
 #pragma unroll
         for (int hh = 0; hh < HP; ++hh)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) qfh[hh][ks] = *reinterpret_cast<const bf16x8*>(qp + hh * DH + ks * 16);
+            for (int ks = 0; ks < NKS; ++ks) {
+#if defined(ATTN_NT) && (ATTN_NT & 2)
+                qfh[hh][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(qp + hh * DH + ks * 16));     // A/B: read-once rows as streaming loads
+#else
+                qfh[hh][ks] = *reinterpret_cast<const bf16x8*>(qp + hh * DH + ks * 16);
+#endif
+            }
 #pragma unroll
         for (int hh = 0; hh < HP; ++hh) {
         const bf16x8 (&qf)[NKS] = qfh[hh];
@@ -254,7 +265,12 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint4 piece = {cw[j][0], cw[j][1], cw[j + 4][0], cw[j + 4][1]};
+#if defined(ATTN_NT) && (ATTN_NT & 1)
+                    { typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                      __builtin_nontemporal_store(u32x4_t{piece.x, piece.y, piece.z, piece.w}, reinterpret_cast<u32x4_t*>(op + 8 * j)); }                                 // A/B: streaming stores of the output rows
+#else
                     *reinterpret_cast<uint4*>(op + 8 * j) = piece;
+#endif
                 }
             }
         } else if (q < Tq) {

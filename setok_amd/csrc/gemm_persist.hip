@@ -773,6 +773,12 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #ifndef PP_GM
 #define PP_GM 8            // M-tiles per group of the tile order (cfg2, same box: 4 = 8; 16: -1 %; 32: -4.7 %)
 #endif
+#ifndef PP_NT_STORE
+#define PP_NT_STORE 1       // 1: the C tile leaves as streaming stores (`nt`); 0: ordinary stores (rounds 1-4).  Round 5, same box, alternating runs: q|k|v +4...5 %,
+#endif                      // out-projection + residual +7 %, fc1 + quick_gelu +3 %, cfg2 step -1.7 %: the tile's 128 KiB no longer pass through the L2 the operand panels live in
+#ifndef PP_RESYNC
+#define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
+#endif
 #ifndef PP_NO_EDGE
 #define PP_NO_EDGE 1        // 1: the host hands this kernel whole 256-row tiles only (the remainder rows go to the small-tile kernel, a device-side M to gemm_persist_kernel)
 #endif
@@ -942,11 +948,19 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     issue_quarter(0, 0); issue_quarter(1, 0); issue_quarter(2, 0); issue_quarter(3, 0); issue_quarter(2, 1); issue_quarter(3, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     bar();
+#if !PP_RESYNC
     if (GRP == 1) bar();                                    // the second wave row runs one slot behind
+#endif
     int ahead = 0;                                          // 1: the A quarters of this tile's K-tile 1 went out in the previous tile's epilogue, ahead of
                                                             // exactly NSTORE + NAUX other entries of the vector-memory queue; 2: ahead of an unknown number
 #ifdef PP_TIMING
     unsigned long long t_init = 0, t_k = 0, t_epi = 0;
+    unsigned long long t_kt0 = 0, t_kt1 = 0, t_kt2 = 0, t_kt3 = 0, t_ktr = 0, t_ktl = 0;     // K-tiles 0..3, the middle ones, the last one
+    unsigned long long t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_pre = 0;                    // epilogue: before pass 0, passes 0..3
+    unsigned long long t_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                      // the eight barrier-to-barrier slots of a tile's LAST K-tile
+#define PPT_SLOT(i) if (kt == nk - 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); t_s[i] += now_ - tsl; tsl = now_; }
+#else
+#define PPT_SLOT(i)
 #endif
     for (;;) {
 #ifdef PP_TIMING
@@ -980,13 +994,26 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #ifdef PP_TIMING
         const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
+#if PP_RESYNC
+        // The one-slot offset between the wave rows is set up PER TILE and taken back at the tile's end (row 0's closing barrier below), so that both
+        // rows run their epilogues at the same time.  Round 5: with the offset set up once per launch, row 1's last barrier of a tile paired with
+        // row 0's FIRST barrier of the next tile — row 1 stood at it through the whole of row 0's epilogue, and row 0 then stood at its second
+        // barrier through the whole of row 1's: the two epilogues of every tile ran one after the other with the matrix pipe idle (s_memtime:
+        // row 0's first K-tile of a tile 7-17 k ticks against 3.2 k for any other, row 1's last slot 4-12 k against 0.45 k).
+        if (GRP == 1) bar();
+#endif
         for (int kt = 0; kt < nk; ++kt) {
+#ifdef PP_TIMING
+            const unsigned long long tkt0 = __builtin_amdgcn_s_memtime();
+            unsigned long long tsl = tkt0;
+#endif
             const char* T = smem + ((cnt + kt) & 1) * STAGE;
             const bool skipA = ahead != 0 && kt == 0;        // (uniform)
             // phase 0
             if (!skipA) issue_quarter(0, kt + 1);
             rd_w(T, 0, W0); rd_a(T, 0, 0, A0[0]);
             bar();
+            PPT_SLOT(0)
             rd_a(T, 0, 1, A0[1]);                           // lands under the first 8 MFMAs
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
@@ -997,26 +1024,31 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             mma8(0, 0, A0[1], W0[1]);
             __builtin_amdgcn_s_setprio(0);
             bar();
+            PPT_SLOT(1)
             // phase 1
             if (!skipA) issue_quarter(1, kt + 1);
             rd_w(T, 1, W1); rd_a(T, 1, 0, A1[0]);
             lgk0();                                         // the last readers of this stage's W quarters retire BEFORE the barrier: phase 2 refills them
             bar();
+            PPT_SLOT(2)
             __builtin_amdgcn_s_setprio(1);
             mma8(0, 1, A0[0], W1[0]);
             mma8(0, 1, A0[1], W1[1]);
             __builtin_amdgcn_s_setprio(0);
             bar();
+            PPT_SLOT(3)
             // phase 2
             issue_quarter(2, kt + 2);
             rd_a(T, 1, 1, A1[1]);
             lgk0();                                         // likewise this stage's A quarters (refilled by the next K-tile's phases 0 / 1, or the epilogue)
             bar();
+            PPT_SLOT(4)
             __builtin_amdgcn_s_setprio(1);
             mma8(1, 1, A1[0], W1[0]);
             mma8(1, 1, A1[1], W1[1]);
             __builtin_amdgcn_s_setprio(0);
             bar();
+            PPT_SLOT(5)
             // phase 3 + the one wait of the K-tile, one slot before the next K-tile's first reader (wave row 0 reads at the next slot boundary:
             // row 0 waits at the end of its MFMA slot, row 1 at the end of its LOAD slot — the same barrier for both)
             issue_quarter(3, kt + 2);
@@ -1028,14 +1060,25 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             };
             if (GRP == 1) wait_next();
             bar();
+            PPT_SLOT(6)
             __builtin_amdgcn_s_setprio(1);
             mma8(1, 0, A1[0], W0[0]);
             mma8(1, 0, A1[1], W0[1]);
             __builtin_amdgcn_s_setprio(0);
             if (GRP == 0) wait_next();
             bar();
+            PPT_SLOT(7)
+#ifdef PP_TIMING
+            {
+                const unsigned long long d = __builtin_amdgcn_s_memtime() - tkt0;
+                if (kt == nk - 1) t_ktl += d; else if (kt == 0) t_kt0 += d; else if (kt == 1) t_kt1 += d; else if (kt == 2) t_kt2 += d; else if (kt == 3) t_kt3 += d; else t_ktr += d;
+            }
+#endif
         }
         // ---- tile boundary ------------------------------------------------------------------------------------------------------------------------
+#if PP_RESYNC
+        if (GRP == 0) bar();                                // pairs with row 1's last barrier of the tile: the rows enter the epilogue together
+#endif
 #ifdef PP_TIMING
         const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1058,11 +1101,38 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             const char* r_wave = reinterpret_cast<const char*>(g.res + (RESK ? wave_elem : 0));
             const unsigned lane_off = (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
             const unsigned row8 = (unsigned)g.ldc * 16u;
+#if PP_NT_STORE
+            const unsigned long long c_wave_s = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)c_wave) |
+                                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)c_wave >> 32)) << 32);
+#endif
             // With a residual: the rows of pass h + 1 are requested inside pass h (ordinary loads: between the epilogue's own loads and stores no
             // LDS-DMA request is issued, so the compiler's counted waits see the queue as it is); pass 0's rows are requested here, FIRST, and the
             // next tile's A quarters go out only after pass 0 has them — requested the other way round, the wait for the rows would also wait for
             // quarters that were asked for a moment ago.
             bf16x8 rv[4];
+#if PP_NT_STORE
+            // The streaming stores are inline assembly, i.e. invisible to the compiler's wait counting: with ordinary residual loads its waits for pass
+            // h + 1's rows would also wait for pass h's stores (and in pass 3 for everything).  So the rows are assembly loads too, and the waits are
+            // counted by hand (res_ready): behind row `it` of pass h the queue holds the rows it + 1 .. 3 of the pass and what the PREVIOUS pass issued
+            // after requesting them — pass 0: its 4 stores + the 4 start-value loads of the next tile; passes 1, 2: 4 stores.
+            const unsigned long long r_wave_s = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)r_wave) |
+                                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)r_wave >> 32)) << 32);
+            auto load_residual = [&](int h) {
+                if constexpr (RESK) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rv[it]) : "v"(lane_off), "s"(r_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
+                }
+            };
+            auto res_ready = [&](int h, int it) {
+                const int n = (3 - it) + (h == 0 ? 0 : h == 1 ? 8 : 4);
+                switch (n) {
+#define PP_RW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" : "+v"(rv[it]) :: "memory"); break;
+                    PP_RW(0) PP_RW(1) PP_RW(2) PP_RW(3) PP_RW(4) PP_RW(5) PP_RW(6) PP_RW(7) PP_RW(8) PP_RW(9) PP_RW(10) PP_RW(11)
+#undef PP_RW
+                }
+            };
+#else
             auto load_residual = [&](int h) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -1070,7 +1140,13 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                     if (interior || grow < Mrt) rv[it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
                 }
             };
+            auto res_ready = [&](int, int) {};
+#endif
             if constexpr (RESK) load_residual(0);
+#ifdef PP_TIMING
+            unsigned long long tp = __builtin_amdgcn_s_memtime();
+            t_pre += tp - ts2;
+#endif
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 float er_pass[2] = {1.f, 1.f};
@@ -1125,9 +1201,11 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                 }
                 if constexpr (RESK) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
+                    for (int it = 0; it < 4; ++it) {
+                        res_ready(h, it);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[it][e]);     // round, THEN add the residual (torch's bf16 semantics)
+                    }
                     if (h == 0) { asm volatile("" ::: "memory"); issue_next_a1(); }
                     if (h + 1 < 4) load_residual(h + 1);          // (all four passes' rows at the top of the epilogue instead: no difference in time; requested
                                                                   //  inside the tile's last K-tile, the rows need 64 registers the K loop does not have: -14 %)
@@ -1141,15 +1219,35 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int grow = m0 + GRP * 128 + h * 32 + it * 8 + lrow;
-                    if (interior || grow < Mrt)
+                    if (interior || grow < Mrt) {
+#if PP_NT_STORE
+                        if constexpr (PP_NT_STORE == 1 || (PP_NT_STORE == 2 && !RESK) || (PP_NT_STORE == 3 && RESK)) {
+                            // streaming store in SGPR-base form (the builtin falls back to 64-bit per-lane addresses)
+                            // (s_nop 1: a VALU write of the data registers of a > 64-bit store needs two wait states behind it on gfx940+ — the compiler's hazard
+                            //  recognizer pads its own stores, it cannot know that this statement is one: without the pad the erf-GELU instantiation, which reuses
+                            //  the registers at once, stored the next element's intermediates — r05_dbg2)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
+                        } else
+#endif
                         *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the staging rows are rewritten by the next pass)
+#ifdef PP_TIMING
+                { const unsigned long long tq = __builtin_amdgcn_s_memtime(); const unsigned long long d = tq - tp; tp = tq;
+                  if (h == 0) t_p0 += d; else if (h == 1) t_p1 += d; else if (h == 2) t_p2 += d; else t_p3 += d; }
+#endif
             }
         }
 #ifdef PP_TIMING
         { const unsigned long long ts3 = __builtin_amdgcn_s_memtime(); t_init += ts1 - ts0; t_k += ts2 - ts1; t_epi += ts3 - ts2; }
         if (!has_next && g.tim && tid == 0) { g.tim[blockIdx.x * 4 + 0] = t_k; g.tim[blockIdx.x * 4 + 1] = t_epi; g.tim[blockIdx.x * 4 + 2] = t_init; g.tim[blockIdx.x * 4 + 3] = (unsigned long long)(round + 1) << 40; }
+        if (!has_next && g.tim && (tid == 0 || tid == 256)) {          // the fine split: wave 0 (row 0) and wave 4 (row 1), behind the coarse table
+            unsigned long long* f = g.tim + 256 * 4 + (blockIdx.x * 2 + (tid >> 8)) * 20;
+            f[0] = t_kt0; f[1] = t_kt1; f[2] = t_kt2; f[3] = t_kt3; f[4] = t_ktr; f[5] = t_ktl; f[6] = t_pre; f[7] = t_p0; f[8] = t_p1; f[9] = t_p2; f[10] = t_p3; f[11] = (unsigned long long)(round + 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[12 + i] = t_s[i];
+        }
 #endif
         if (!has_next) break;
         ahead = interior ? 1 : 2;
@@ -1158,7 +1256,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
         has_next = tile_of(round + 1, nm0, nn0);
         if (has_next) tile_ptrs(nm0, nn0, a_nxt, w_nxt, edge_nxt, lim_nxt);
     }
+#if !PP_RESYNC
     if (GRP == 0) bar();                                    // matches the second row's last barrier
+#endif
 }
 
 template <int ACT, bool LNK, bool RESK = false>
@@ -1274,7 +1374,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int tm_main = tilesM - p;
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
-    if (timing && !tim) { if (hipMalloc(&tim, 256 * 4 * 8) != hipSuccess) tim = nullptr; }
+    if (timing && !tim) { if (hipMalloc(&tim, (256 * 4 + 256 * 2 * 20) * 8) != hipSuccess) tim = nullptr; else (void)hipMemset(tim, 0, (256 * 4 + 256 * 2 * 20) * 8); }
     PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1,
             ln_stats, ln_colsum, m_dev};
     if (!bias || ln_stats) {
@@ -1293,6 +1393,20 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
             for (int i = 0; i < nb; ++i) { a += h[i * 4]; b += h[i * 4 + 1]; c += h[i * 4 + 2]; r += (double)(h[i * 4 + 3] >> 40); bar += (double)(h[i * 4 + 3] & ((1ull << 40) - 1)); }
             fprintf(stderr, "[gemm timing] M=%d N=%d K=%d tiles/block=%.2f  per tile: main %.0f cyc (vmcnt waits %.0f, barrier waits %.0f), epilogue %.0f cyc\n",
                     M, N, K, r / nb, a / r, c / r, bar / r, b / r);
+#ifdef PP_TIMING
+            static unsigned long long hf[256 * 2 * 20];
+            if (hipMemcpy(hf, tim + 256 * 4, sizeof(hf), hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int row = 0; row < 2; ++row) {
+                    double s[11] = {0}, sl[8] = {0}, rr = 0;
+                    for (int i = 0; i < nb; ++i) { const unsigned long long* f = hf + (i * 2 + row) * 20; for (int k = 0; k < 11; ++k) s[k] += (double)f[k]; rr += (double)f[11]; for (int k = 0; k < 8; ++k) sl[k] += (double)f[12 + k]; }
+                    if (rr > 0)
+                        fprintf(stderr, "[gemm timing fine] wave row %d: K-tile 0 %.0f, 1 %.0f, 2 %.0f, 3 %.0f, middle (each of %d) %.0f, last %.0f | epilogue: pre %.0f, pass0 %.0f, pass1 %.0f, pass2 %.0f, pass3 %.0f\n",
+                                row, s[0] / rr, s[1] / rr, s[2] / rr, s[3] / rr, K / TK - 5, (K / TK > 5 ? s[4] / rr / (K / TK - 5) : 0.0), s[5] / rr, s[6] / rr, s[7] / rr, s[8] / rr, s[9] / rr, s[10] / rr);
+                    if (rr > 0)
+                        fprintf(stderr, "[gemm timing last] wave row %d: slots of the last K-tile %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", row, sl[0] / rr, sl[1] / rr, sl[2] / rr, sl[3] / rr, sl[4] / rr, sl[5] / rr, sl[6] / rr, sl[7] / rr);
+                }
+            }
+#endif
         }
     }
     if (rc != SETOK_OK || p == 0) return rc;

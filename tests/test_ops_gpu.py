@@ -61,7 +61,12 @@ def test_linear_bf16(M, N, K, act):
 @pytest.mark.parametrize("M,N,K,act,res", [(4096, 4096, 1024, 1, True), (4100, 2056, 128, 0, False), (2560, 3072, 256, 2, True),
                                            (6000, 1024, 4096, 0, True), (8448, 2048, 512, 1, True), (65792, 1024, 128, 0, True),
                                            (16640, 4096, 64, 2, False), (4100, 2112, 192, 0, True), (6000, 1024, 256, 1, False),
-                                           (25700, 1344, 320, 2, True), (66000, 768, 768, 0, True)])
+                                           (25700, 1344, 320, 2, True), (66000, 768, 768, 0, True),
+                                           # round 5: every activation x residual combination on the ping-pong kernel (N a multiple of 256, K >= 128) —
+                                           # the erf-GELU form without a residual had no case here, and it is the one whose epilogue reuses the store
+                                           # registers at once (the streaming stores' wait states, gemm_persist.hip)
+                                           (7776, 3072, 768, 2, False), (8192, 4096, 1024, 2, False), (7680, 768, 3072, 1, True), (7776, 768, 768, 2, True),
+                                           (23040, 2304, 768, 1, False), (7680, 1024, 1024, 0, False)])
 def test_linear_bf16_large_tiles(M, N, K, act, res):
     """Shapes with >= 96 output tiles take the 256x256 direct-to-LDS kernel (ragged M and N edges included)."""
     a, w = _rand(M, K, seed=1).bfloat16(), (_rand(N, K, seed=2, scale=K ** -0.5)).bfloat16()
