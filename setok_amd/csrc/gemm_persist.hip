@@ -943,6 +943,10 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(nbv[0]), "+v"(nbv[1]), "+v"(nbv[2]), "+v"(nbv[3]) : [n] "n"(NBEHIND) : "memory");
     };
 
+    // (Round 5: the 14 start-value loads per wave of the folded LayerNorm — 112 of a tile's ~270 vector-memory instructions in an epilogue that is bound
+    //  by the CU's address unit — were replaced by three LDS-DMA pieces per wave into the wave's idle epilogue staging, read back in pass 0.  Two
+    //  findings: a counted vmcnt wait alone does NOT make a wave's own LDS-DMA data readable — it takes the barrier behind it that the K loop has
+    //  anyway (without it: old bytes now and then) — and with that barrier the change is worth nothing: 42.98 against 42.85 ms.  Not kept.)
     // ---- start of the stream: the first tile's start values, K-tile 0 entirely + the W quarters of K-tile 1 --------------------------------------
     load_start(n0, m0);
     issue_quarter(0, 0); issue_quarter(1, 0); issue_quarter(2, 0); issue_quarter(3, 0); issue_quarter(2, 1); issue_quarter(3, 1);
@@ -1110,29 +1114,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             // next tile's A quarters go out only after pass 0 has them — requested the other way round, the wait for the rows would also wait for
             // quarters that were asked for a moment ago.
             bf16x8 rv[4];
-#if PP_NT_STORE
-            // The streaming stores are inline assembly, i.e. invisible to the compiler's wait counting: with ordinary residual loads its waits for pass
-            // h + 1's rows would also wait for pass h's stores (and in pass 3 for everything).  So the rows are assembly loads too, and the waits are
-            // counted by hand (res_ready): behind row `it` of pass h the queue holds the rows it + 1 .. 3 of the pass and what the PREVIOUS pass issued
-            // after requesting them — pass 0: its 4 stores + the 4 start-value loads of the next tile; passes 1, 2: 4 stores.
-            const unsigned long long r_wave_s = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)r_wave) |
-                                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)r_wave >> 32)) << 32);
-            auto load_residual = [&](int h) {
-                if constexpr (RESK) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rv[it]) : "v"(lane_off), "s"(r_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
-                }
-            };
-            auto res_ready = [&](int h, int it) {
-                const int n = (3 - it) + (h == 0 ? 0 : h == 1 ? 8 : 4);
-                switch (n) {
-#define PP_RW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" : "+v"(rv[it]) :: "memory"); break;
-                    PP_RW(0) PP_RW(1) PP_RW(2) PP_RW(3) PP_RW(4) PP_RW(5) PP_RW(6) PP_RW(7) PP_RW(8) PP_RW(9) PP_RW(10) PP_RW(11)
-#undef PP_RW
-                }
-            };
-#else
+            // (The residual rows stay ORDINARY loads although the streaming stores below are inline assembly the compiler's wait counting cannot see: its
+            //  counts are then too small — a wait for pass h + 1's rows also waits for pass h's stores — which is safe and costs nothing measurable.
+            //  Assembly loads with hand-counted waits were built: the same speed, and the -DPP_TIMING build of that form faulted; not kept.)
             auto load_residual = [&](int h) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -1140,8 +1124,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                     if (interior || grow < Mrt) rv[it] = *reinterpret_cast<const bf16x8*>(r_wave + (size_t)(h * 4 + it) * row8 + lane_off);
                 }
             };
-            auto res_ready = [&](int, int) {};
-#endif
+
             if constexpr (RESK) load_residual(0);
 #ifdef PP_TIMING
             unsigned long long tp = __builtin_amdgcn_s_memtime();
@@ -1201,11 +1184,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                 }
                 if constexpr (RESK) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        res_ready(h, it);
+                    for (int it = 0; it < 4; ++it)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ov[it][e] = (bf16)((float)ov[it][e] + (float)rv[it][e]);     // round, THEN add the residual (torch's bf16 semantics)
-                    }
                     if (h == 0) { asm volatile("" ::: "memory"); issue_next_a1(); }
                     if (h + 1 < 4) load_residual(h + 1);          // (all four passes' rows at the top of the epilogue instead: no difference in time; requested
                                                                   //  inside the tile's last K-tile, the rows need 64 registers the K loop does not have: -14 %)
