@@ -94,17 +94,27 @@ def no_backward(what: str, value, deps: Iterable[Any]):
 _WARNED: set = set()
 
 
-def warn_no_grad_once(what: str, tensors: Iterable[Any], why: str) -> None:
+def warn_no_grad_once(what: str, tensors: Iterable[Any], why: str, owner: Any = None, inputs: Iterable[Any] = ()) -> None:
     """For a module whose REFERENCE forward is itself `@torch.no_grad()` (the CLIP tower, clip_encoder.py:50): parameters that require a
-    gradient get none there either, so the call proceeds exactly like the reference's — with one warning per process saying so."""
-    if not torch.is_grad_enabled() or what in _WARNED:
+    gradient get none there either, so the call proceeds exactly like the reference's — with one warning PER MODULE INSTANCE (`owner`; keyed
+    by name alone, a second tower with unfrozen parameters went through silently: ADVICE r04) saying so.  `inputs` (e.g. the images) that
+    require a gradient get a warning of their own, worded for what it is."""
+    if not torch.is_grad_enabled():
         return
-    for t in tensors:
-        if isinstance(t, torch.Tensor) and t.requires_grad:
-            import warnings
-            _WARNED.add(what)
-            warnings.warn(f"{what}: gradients are enabled and a parameter requires one, but {why}; running without a graph.", UserWarning, stacklevel=3)
-            return
+    import warnings
+    key = (what, id(owner) if owner is not None else None)
+    if key + ("params",) not in _WARNED:
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                _WARNED.add(key + ("params",))
+                warnings.warn(f"{what}: gradients are enabled and a parameter requires one, but {why}; running without a graph.", UserWarning, stacklevel=3)
+                break
+    if key + ("inputs",) not in _WARNED:
+        for t in inputs:
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                _WARNED.add(key + ("inputs",))
+                warnings.warn(f"{what}: an INPUT requires a gradient, but {why}; no gradient will reach it.", UserWarning, stacklevel=3)
+                break
 
 
 def _grad_as(g: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:

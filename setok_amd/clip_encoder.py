@@ -218,7 +218,8 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
         if not self.is_loaded:
             raise RuntimeError("vision tower not loaded: call load_model() first")
         autograd.warn_no_grad_once("CLIPVisionTower", self.vision_tower.parameters(),
-                                   "the tower's forward is @torch.no_grad() in the reference (clip_encoder.py:50) and has no backward pass on the HIP path")
+                                   "the tower's forward is @torch.no_grad() in the reference (clip_encoder.py:50) and has no backward pass on the HIP path",
+                                   owner=self, inputs=[images])
         with torch.no_grad():
             return self._hidden_rows(images)
 

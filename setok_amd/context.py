@@ -158,11 +158,24 @@ class GraphedEncode:
         """Has the module this graph was captured from moved on (new weights / dtype / device / layer selection)?"""
         return self.tok is not None and self.tok._context() is not self.ctx
 
+    def refresh(self) -> bool:
+        """Re-capture now if the module has moved on; returns whether it did.  A re-capture SYNCHRONISES the device (warm-up call + capture), so
+        a caller that is itself inside a capture, or that wants to choose the moment, calls this outside its critical section; __call__ does it
+        implicitly otherwise."""
+        if self.tok is None:
+            return False
+        ctx = self.tok._context()                                                      # ONE look-up per call (the key walks every parameter's version)
+        if ctx is self.ctx:
+            return False
+        self.graph = self.out = None
+        self._capture(ctx)
+        return True
+
     def __call__(self, images: torch.Tensor):
-        """-> (packed tokens (sum L_i, D) — a fresh tensor —, counts list, idx_cluster, score, index_down) like EncodeContext.encode."""
-        if self.stale():
-            self.graph = self.out = None
-            self._capture(self.tok._context())
+        """-> (packed tokens (sum L_i, D) — a fresh tensor —, counts list, idx_cluster, score, index_down) like EncodeContext.encode.
+        If the module's weights / dtype / device / layer selection changed since the capture, the graph is re-captured first (see refresh():
+        that synchronises the device)."""
+        self.refresh()
         assert tuple(images.shape) == tuple(self.images.shape)
         self.images.copy_(images, non_blocking=True)
         self.graph.replay()

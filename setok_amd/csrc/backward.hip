@@ -199,7 +199,7 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ pre, const T* __restrict__
 // dx = gelu'(pre) * drop(dy): the backward of Mlp's `drop(act(fc1 x))` in one pass.  drop(dy) is rounded to `dtype` first, as the two-launch form
 // (setok_dropout on the gradient in place, then setok_gelu_bwd) rounds it: identical bits.
 template <typename T>
-__global__ void gelu_bwd_dropout_kernel(const T* __restrict__ pre, const T* __restrict__ dy, T* __restrict__ dx, int64_t n, float scale, unsigned thresh16,
+__global__ void gelu_bwd_dropout_kernel(const T* __restrict__ pre, const T* dy, T* dx, int64_t n, float scale, unsigned thresh16,        // dx may BE dy (training.py): no __restrict__ on the pair
                                         unsigned long long seed, unsigned long long offset) {
     constexpr int V = Elem<T>::VEC;
     const int64_t nvec = n / V;

@@ -12,6 +12,7 @@
 // mask[i,j] = rho_j > rho_i and the row-j-max quirk (:96-99), score = delta * rho (:101), first-min
 // argmin over centre rows (:111-113), centres own themselves (:117-119).
 #include "common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <math.h>
 
@@ -1307,16 +1308,26 @@ extern "C" int setok_cluster_dpc_knn(void* stream, int dtype, const void* x, int
         // (a CPX partition reports its own 32); a CU mask on the stream or the process (hipExtStreamCreateWithCUMask, ROC_GLOBAL_CU_MASK) cuts it down.
         int ncu = 256, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-        if (!capturing) {                                                 // (a stream query is not something to issue under capture; a captured graph runs unmasked)
+        // The CU mask is a host-side property of the stream: queried under capture too (round 5, ADVICE r04: a graph captured on — or for — a
+        // CU-masked stream was sized from the device's CU count and could launch more spin-waiting workgroups than can be co-resident).  Should the
+        // runtime refuse the query while capturing, the smallest mask an earlier eager call saw on this device stands in (GraphedEncode's warm-up
+        // call runs on the capture's stream just before the capture).
+        static std::atomic<int> seen_masked[64];                          // per device: 0 = nothing seen
+        {
             uint32_t mask[32] = {0};
+            int bits = 0;
             if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
-                int bits = 0;
                 for (int i = 0; i < 32; ++i) bits += __builtin_popcount(mask[i]);
-                if (bits > 0 && bits < ncu) ncu = bits;
+                if (bits > 0 && bits < ncu) {
+                    ncu = bits;
+                    if (dev >= 0 && dev < 64) { int prev = seen_masked[dev].load(); while ((prev == 0 || bits < prev) && !seen_masked[dev].compare_exchange_weak(prev, bits)) {} }
+                }
             } else {
                 (void)hipGetLastError();
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+                const int prev = (dev >= 0 && dev < 64) ? seen_masked[dev].load() : 0;
+                if (capturing && prev > 0 && prev < ncu) ncu = prev;
             }
         }
         if (const char* e = getenv("SETOK_STRIP_GRID")) {                 // tests / small-device rehearsal: cap the grid (read per call)

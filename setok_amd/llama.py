@@ -125,6 +125,29 @@ class LlamaModel(PackCacheMixin, nn.Module):
         return ops.rmsnorm(x, pk["norm"], self.eps, out=y).reshape(B, T, D)
 
 
+def _refuse_unsupported_llama_fields(g) -> None:
+    """The prefill reads hidden / intermediate sizes, layer and head counts, `num_key_value_heads`, `rms_norm_eps` and `rope_theta` — plain
+    multi-head or grouped-query Llama (Vicuna-7B, the reference's LLM: scripts/finetune.sh).  A checkpoint whose config carries anything
+    that changes the arithmetic beyond that would load cleanly and give wrong logits, so it is refused here:
+    `rope_scaling` (llama3 / linear / dynamic / yarn: other inverse frequencies at every position), an explicit `head_dim` that is not
+    hidden_size / num_attention_heads, `attention_bias` / `mlp_bias` (the fused q|k|v, gate|up and down projections have no bias input),
+    and a `sliding_window` (checked against the sequence length in forward: a window that covers the prompt is plain causal attention)."""
+    for key in ("rope_scaling", "rope_parameters"):                         # (`rope_parameters`: the name newer HF configs carry the same dict under)
+        rs = g(key)
+        if rs is None:
+            continue
+        kind = (rs.get("rope_type", rs.get("type")) if isinstance(rs, dict) else getattr(rs, "rope_type", getattr(rs, "type", rs)))
+        if kind not in (None, "default"):
+            raise NotImplementedError(f"SetokimLlamaPrefill: {key}={rs!r} is not implemented on the HIP path (only the plain rotary "
+                                      "embedding with `rope_theta`): a Llama-3.1-style checkpoint would give wrong logits")
+    hd, H, D = g("head_dim"), g("num_attention_heads"), g("hidden_size")
+    if hd is not None and int(hd) != int(D) // int(H):
+        raise NotImplementedError(f"SetokimLlamaPrefill: head_dim={hd} != hidden_size / num_attention_heads = {int(D) // int(H)} is not implemented")
+    for k in ("attention_bias", "mlp_bias"):
+        if g(k, False):
+            raise NotImplementedError(f"SetokimLlamaPrefill: {k}=True is not implemented (the projections are loaded without a bias)")
+
+
 class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
     """`SetokimLlamaForCausalLM.forward` without the loss (setokim_llama.py:94-143): splice the image tokens into the text embeddings,
     run the LLM over them, project to the vocabulary.  `vision_tower` / `mm_in_projector` are the SetokTokenizer and projector of the
@@ -134,6 +157,7 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
         super().__init__()
         g = lambda k, d=None: config_get(config, k, d)
         self.config = config
+        _refuse_unsupported_llama_fields(g)
         self.model = LlamaModel(g("vocab_size"), g("hidden_size"), g("intermediate_size"), g("num_hidden_layers"), g("num_attention_heads"),
                                 g("num_key_value_heads", g("num_attention_heads")), g("rms_norm_eps", 1e-5), g("rope_theta", 10000.0))
         self.lm_head = nn.Linear(g("hidden_size"), g("vocab_size"), bias=False)
@@ -171,6 +195,10 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
                     b, t = divmod(int(st[1]), input_ids.shape[1])
                     raise IndexError(f"index out of range in self: input_ids[{b}, {t}] = {int(input_ids[b, t])} is not a row of the "
                                      f"{w_e.shape[0]}-row embedding table (and no images were passed for image placeholders)")
+        sw = config_get(self.config, "sliding_window")
+        if sw is not None and int(sw) < inputs_embeds.shape[1]:
+            raise NotImplementedError(f"SetokimLlamaPrefill: sliding_window={sw} is shorter than the sequence ({inputs_embeds.shape[1]} positions): "
+                                      "windowed attention is not implemented on the HIP path")
         hidden = self.model(inputs_embeds, attention_mask, position_ids)           # setokim_llama.py:130-140
         B, T, D = hidden.shape
         w = self.lm_head.weight.detach().contiguous()

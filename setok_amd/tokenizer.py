@@ -398,8 +398,9 @@ class SetokTokenizer(nn.Module):
         B = x.shape[0]
         tower = self.image_feature_encoder
         if tower.is_loaded:                                                        # images / tower parameters get no gradient, as in the reference (clip_encoder.py:50)
-            autograd.warn_no_grad_once("CLIPVisionTower", [x, *tower.vision_tower.parameters()],
-                                       "the tower's forward is @torch.no_grad() in the reference (clip_encoder.py:50) and has no backward pass on the HIP path")
+            autograd.warn_no_grad_once("CLIPVisionTower", tower.vision_tower.parameters(),
+                                       "the tower's forward is @torch.no_grad() in the reference (clip_encoder.py:50) and has no backward pass on the HIP path",
+                                       owner=tower, inputs=[x])
         training_head = autograd.grad_needed(*[p for n, p in self.named_parameters() if not n.startswith("image_feature_encoder.")])
         if training_head or os.environ.get("SETOK_HOST_PATH", "0") == "1":        # SETOK_HOST_PATH: the same path op by op from Python (A/B runs, tests of the two forms)
             hidden = tower.hidden_rows(x)                                          # tokenizer.py:161

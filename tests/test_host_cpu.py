@@ -193,3 +193,49 @@ def test_tokenizer_copies_do_not_share_the_library_context():
         assert "_ctx" not in clone.__dict__ and "_ctx_params" not in clone.__dict__
         assert torch.equal(clone.out.weight, tok.out.weight)
     assert "_ctx" in tok.__dict__
+
+
+def test_llama_prefill_refuses_config_fields_it_would_silently_ignore():
+    """only num_key_value_heads and rope_theta are read beyond the plain Llama sizes; a config that changes the arithmetic in any
+    other way (rope_scaling, an explicit head_dim, projection biases) must not load and give wrong logits."""
+    from setok_amd.llama import SetokimLlamaPrefill
+    base = dict(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                rms_norm_eps=1e-5, rope_theta=10000.0)
+    SetokimLlamaPrefill(dict(base))                                                          # plain grouped-query Llama: fine
+    SetokimLlamaPrefill(dict(base, rope_scaling=None, head_dim=8, attention_bias=False, mlp_bias=False, sliding_window=None))
+    SetokimLlamaPrefill(dict(base, rope_scaling={"rope_type": "default"}))
+    for bad in (dict(rope_scaling={"rope_type": "llama3", "factor": 8.0}), dict(rope_scaling={"type": "linear", "factor": 2.0}),
+                dict(head_dim=16), dict(attention_bias=True), dict(mlp_bias=True)):
+        with pytest.raises(NotImplementedError):
+            SetokimLlamaPrefill(dict(base, **bad))
+
+    class Cfg:                                                                               # attribute-style configs (HF) are read the same way
+        pass
+    c = Cfg()
+    for k, v in dict(base, rope_scaling={"rope_type": "yarn", "factor": 4.0}).items():
+        setattr(c, k, v)
+    with pytest.raises(NotImplementedError):
+        SetokimLlamaPrefill(c)
+
+
+def test_no_grad_warning_is_per_module_instance_and_words_inputs_separately():
+    """keyed by name alone the first warning silenced every other tower of the process, and an image that requires a gradient
+    produced (or swallowed) the message about parameters."""
+    import warnings
+    from setok_amd import autograd
+    a, b = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    x = torch.zeros(1, 2, requires_grad=True)
+    why = "there is no backward pass"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        autograd.warn_no_grad_once("Tower", a.parameters(), why, owner=a)
+        autograd.warn_no_grad_once("Tower", a.parameters(), why, owner=a)                    # same instance: once
+        autograd.warn_no_grad_once("Tower", b.parameters(), why, owner=b)                    # another instance: its own warning
+        autograd.warn_no_grad_once("Tower", [p.detach() for p in b.parameters()], why, owner=object(), inputs=[x])
+    msgs = [str(m.message) for m in w]
+    assert len(msgs) == 3
+    assert sum("a parameter requires one" in m for m in msgs) == 2 and sum("an INPUT requires a gradient" in m for m in msgs) == 1
+    with warnings.catch_warnings(record=True) as w, torch.no_grad():
+        warnings.simplefilter("always")
+        autograd.warn_no_grad_once("Tower", torch.nn.Linear(2, 2).parameters(), why, owner=object())
+    assert len(w) == 0                                                                       # gradients disabled: nothing to say
