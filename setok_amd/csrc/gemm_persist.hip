@@ -776,6 +776,30 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #ifndef PP_NT_STORE
 #define PP_NT_STORE 1       // 1: the C tile leaves as streaming stores (`nt`); 0: ordinary stores (rounds 1-4).  Round 5, same box, alternating runs: q|k|v +4...5 %,
 #endif                      // out-projection + residual +7 %, fc1 + quick_gelu +3 %, cfg2 step -1.7 %: the tile's 128 KiB no longer pass through the L2 the operand panels live in
+// cache-policy bits of the ping-pong kernel's memory instructions as A/B switches (the vendor's tuned kernels carry such a digit per operand):
+// a bit mask 1 = sc0, 2 = nt, 4 = sc1 for the A requests (PP_PA), the W requests (PP_PW) and the C stores (PP_PC)
+#ifndef PP_PA
+#define PP_PA 0
+#endif
+#ifndef PP_PW
+#define PP_PW 0
+#endif
+#ifndef PP_PC
+#define PP_PC 2
+#endif
+#define PP_POLSTR_0 ""
+#define PP_POLSTR_1 " sc0"
+#define PP_POLSTR_2 " nt"
+#define PP_POLSTR_3 " sc0 nt"
+#define PP_POLSTR_4 " sc1"
+#define PP_POLSTR_5 " sc0 sc1"
+#define PP_POLSTR_6 " sc1 nt"
+#define PP_POLSTR_7 " sc0 sc1 nt"
+#define PP_POLCAT(n) PP_POLSTR_##n
+#define PP_POLSTR(n) PP_POLCAT(n)
+#define PP_POL_A PP_POLSTR(PP_PA)
+#define PP_POL_W PP_POLSTR(PP_PW)
+#define PP_POL_C PP_POLSTR(PP_PC)
 #ifndef PP_RESYNC
 #define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
 #endif
@@ -819,15 +843,22 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     const unsigned a_off = (unsigned)prow * (unsigned)(g.lda * 2) + kc16;
     const unsigned w_off = (unsigned)prow * (unsigned)(g.K * 2) + kc16;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
-    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) {
+    // (PP_POL_A / PP_POL_W: cache-policy bits of the operand requests — "", " nt", " sc0", " sc1" and their combinations — as A/B switches)
+    auto dma16_pol = [&](auto is_w, const char* base, unsigned off, unsigned lds_dst) {
         unsigned keep;
         const unsigned long long b64 = (unsigned long long)base;
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
         const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
         const unsigned long long sb64 = (unsigned long long)lo | ((unsigned long long)hi32 << 32);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
+        if constexpr (decltype(is_w)::value)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" PP_POL_W "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" PP_POL_A "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(sb64), "s"(lds_dst) : "memory");
     };
+    auto dma16 = [&](const char* base, unsigned off, unsigned lds_dst) { dma16_pol(std::false_type{}, base, off, lds_dst); };
+    auto dma16w = [&](const char* base, unsigned off, unsigned lds_dst) { dma16_pol(std::true_type{}, base, off, lds_dst); };
     int m0, n0, nm0 = 0, nn0 = 0, round = 0;
     if (!tile_of(0, m0, n0)) return;
     bool has_next = tile_of(1, nm0, nn0);
@@ -853,8 +884,8 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
         const unsigned sb = lds0 + stage * STAGE + (q >> 1) * BOFF + (q & 1) * QT;
         if (q >> 1) {
             const char* base = wt + (q & 1) * w_half + (size_t)u * 128;
-            dma16(base, w_off, sb);
-            dma16(base + w_piece, w_off, sb + 8192);
+            dma16w(base, w_off, sb);
+            dma16w(base + w_piece, w_off, sb + 8192);
         } else if (PP_NO_EDGE || !edge) {
             const char* base = at + (q & 1) * a_half + (size_t)u * 128;
             dma16(base, a_off, sb);
@@ -1207,7 +1238,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                             // (s_nop 1: a VALU write of the data registers of a > 64-bit store needs two wait states behind it on gfx940+ — the compiler's hazard
                             //  recognizer pads its own stores, it cannot know that this statement is one: without the pad the erf-GELU instantiation, which reuses
                             //  the registers at once, stored the next element's intermediates — r05_dbg2)
-                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
                         } else
 #endif
                         *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];
