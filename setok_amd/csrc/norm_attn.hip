@@ -5,6 +5,20 @@
 // LayerNorm: one wave per row, fp32 statistics (two-pass: mean, then centred variance).
 // Bandwidth-bound: 16-byte accesses, row re-reads hit L1.
 // --------------------------------------------------------------------------------------------
+// The two per-element steps of every LayerNorm kernel here, with their fused multiply-adds written out and nothing else contracted: left to the
+// compiler the generic kernel and a register-resident one rounded a row's centred sum of squares differently now and then (round 5: 10 rows of
+// 7776 at C = 768 differed in one element) — a row alone (generic kernel) must equal the row in a batch.
+__device__ inline float ln_sq_acc(float x, float mean, float q) {
+#pragma clang fp contract(off)
+    const float d = x - mean;
+    return __builtin_fmaf(d, d, q);
+}
+__device__ inline float ln_apply(float x, float mean, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+    const float t = (x - mean) * rstd;
+    return __builtin_fmaf(t, g, b);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* y,
@@ -28,13 +42,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
     for (int c = lane * V; c < C; c += 64 * V) {
         ld_vec<T>(xr + c, buf);
 #pragma unroll
-        for (int i = 0; i < V; ++i) { const float d = buf[i] - mean; q += d * d; }
+        for (int i = 0; i < V; ++i) q = ln_sq_acc(buf[i], mean, q);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
     for (int c = lane * V; c < C; c += 64 * V) {
         ld_vec<T>(xr + c, buf);
 #pragma unroll
-        for (int i = 0; i < V; ++i) buf[i] = (buf[i] - mean) * rstd * gamma[c + i] + beta[c + i];
+        for (int i = 0; i < V; ++i) buf[i] = ln_apply(buf[i], mean, rstd, gamma[c + i], beta[c + i]);
         st_vec<T>(yr + c, buf);
     }
 }
@@ -42,51 +56,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, const float*
 // Rows of C = NCH * 64 * VEC elements (ViT-L: 1024 bf16 = 2 chunks per lane): the row stays in registers between the three passes, and a
 // wave keeps ITS columns of gamma / beta in registers across the rows it walks (read per row they are 4x the row's own bytes through L1).
 // Same arithmetic and summation order as the generic kernel above (results are bit-identical).
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const float* __restrict__ gamma,
+template <typename T, int NCH, int CT = NCH * 64 * Elem<T>::VEC>        // CT: the row length when it is not a whole number of 64-lane chunks (768, 1280: the
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* x, const float* __restrict__ gamma,      // decoder's widths) — the lanes past the end of the last chunk sit out
                                                              const float* __restrict__ beta, T* y, int rows, float eps,
                                                              const int32_t* __restrict__ rows_dev) {
-    constexpr int V = Elem<T>::VEC, C = NCH * 64 * V;
+    constexpr int V = Elem<T>::VEC, C = CT;
+    static_assert(CT % V == 0 && CT <= NCH * 64 * V && CT > (NCH - 1) * 64 * V, "CT: a multiple of the vector width inside the last chunk");
     const int lane = threadIdx.x & 63;
     const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     if (rows_dev) rows = min(rows, *rows_dev);
     if (wave0 >= rows) return;
+    const bool last_ok = ((NCH - 1) * 64 + lane) * V < CT;              // does this lane hold elements of the last chunk?
     float g[NCH][V], b[NCH][V];
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
-        for (int i = 0; i < V; ++i) { g[k][i] = gamma[(k * 64 + lane) * V + i]; b[k][i] = beta[(k * 64 + lane) * V + i]; }
+        for (int i = 0; i < V; ++i) {
+            const bool ok = k < NCH - 1 || last_ok;
+            g[k][i] = ok ? gamma[(k * 64 + lane) * V + i] : 0.f; b[k][i] = ok ? beta[(k * 64 + lane) * V + i] : 0.f;
+        }
     for (int row = wave0; row < rows; row += nwaves) {
         const T* xr = x + (int64_t)row * C;
         T* yr = y + (int64_t)row * C;
         float buf[NCH][V];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) ld_vec<T>(xr + (k * 64 + lane) * V, buf[k]);
+        for (int k = 0; k < NCH; ++k) {
+            if (k < NCH - 1 || last_ok) ld_vec<T>(xr + (k * 64 + lane) * V, buf[k]);
+            else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) buf[k][i] = 0.f;
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
 #pragma unroll
-            for (int i = 0; i < V; ++i) s += buf[k][i];
+            for (int i = 0; i < V; ++i) if (k < NCH - 1 || last_ok) s += buf[k][i];
         const float mean = wave_sum(s) / (float)C;
         float q = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
 #pragma unroll
-            for (int i = 0; i < V; ++i) { const float d = buf[k][i] - mean; q += d * d; }
+            for (int i = 0; i < V; ++i) if (k < NCH - 1 || last_ok) q = ln_sq_acc(buf[k][i], mean, q);
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) buf[k][i] = (buf[k][i] - mean) * rstd * g[k][i] + b[k][i];
-            st_vec<T>(yr + (k * 64 + lane) * V, buf[k]);
+            for (int i = 0; i < V; ++i) buf[k][i] = ln_apply(buf[k][i], mean, rstd, g[k][i], b[k][i]);
+            if (k < NCH - 1 || last_ok) st_vec<T>(yr + (k * 64 + lane) * V, buf[k]);
         }
     }
 }
 
-template <typename T, int NCH>
+template <typename T, int NCH, int CT = NCH * 64 * Elem<T>::VEC>
 static void launch_ln_rows(hipStream_t s, const void* x, const float* gamma, const float* beta, void* y, int rows, float eps, const int32_t* rows_dev) {
     const int grid = min(cdiv(rows, 4), 256 * 8);
-    layernorm_rows_kernel<T, NCH><<<grid, 256, 0, s>>>((const T*)x, gamma, beta, (T*)y, rows, eps, rows_dev);
+    layernorm_rows_kernel<T, NCH, CT><<<grid, 256, 0, s>>>((const T*)x, gamma, beta, (T*)y, rows, eps, rows_dev);
 }
 
 // rows_dev: optional device-side row count (<= rows); rows beyond it are neither read nor written.
@@ -97,8 +122,10 @@ int setok_layernorm_dev(void* stream, int dtype, const void* x, const float* gam
     if (rows == 0) return SETOK_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(rows, 4));
-    if (dtype == SETOK_BF16 && (C == 512 || C == 1024 || C == 1536 || C == 2048) && rows >= 1024) {
+    if (dtype == SETOK_BF16 && (C == 512 || C == 768 || C == 1024 || C == 1280 || C == 1536 || C == 2048) && rows >= 1024) {
         if (C == 512) launch_ln_rows<bf16, 1>(s, x, gamma, beta, y, rows, eps, rows_dev);
+        else if (C == 768) launch_ln_rows<bf16, 2, 768>(s, x, gamma, beta, y, rows, eps, rows_dev);         // round 5: the reconstruction decoder's width (cfg3: 49 LayerNorms of
+        else if (C == 1280) launch_ln_rows<bf16, 3, 1280>(s, x, gamma, beta, y, rows, eps, rows_dev);       //  82 944 x 768 per step ran on the generic kernel at 4.2 TB/s)
         else if (C == 1024) launch_ln_rows<bf16, 2>(s, x, gamma, beta, y, rows, eps, rows_dev);
         else if (C == 1536) launch_ln_rows<bf16, 3>(s, x, gamma, beta, y, rows, eps, rows_dev);
         else launch_ln_rows<bf16, 4>(s, x, gamma, beta, y, rows, eps, rows_dev);

@@ -263,7 +263,7 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
     # -- weight packing: fused q|k|v (self) and k|v (cross) projections, fp32 biases / LayerNorm affine ------------------
     def _pack(self):
         w = self.mapper_fc_in.weight
-        key = (w.dtype, str(w.device), self._versions(self.parameters()))
+        key = (w.dtype, str(w.device), os.environ.get("SETOK_LN_FOLD", "1"), self._versions(self.parameters()))
         if self._packed.get("key") == key:
             return self._packed
         lin = lambda m: (m.weight.detach().contiguous(), _f32(m.bias))
@@ -280,6 +280,15 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
             layers.append(d)
         blocks = [dict(n1=ln(b.norm1), qkv=lin(b.attn.qkv), proj=lin(b.attn.proj), n2=ln(b.norm2), fc1=lin(b.mlp.fc1),
                        fc2=lin(b.mlp.fc2)) for b in self.pixel_decoder]
+        # bf16 throughput mode (round 5): norm1 / norm2 of the pixel decoder's pre-LN blocks are folded into the qkv and fc1 GEMMs exactly as the
+        # tower's layer_norm1 / layer_norm2 are (ops.linear_ln: the GEMM streams the raw rows, a statistics pass replaces the LayerNorm's
+        # read + write); SETOK_LN_FOLD=0 keeps the separate LayerNorm (A/B runs); the fp32 parity mode always does.
+        D = self.decoder_embed_dim
+        if w.dtype == torch.bfloat16 and w.device.type == "cuda" and os.environ.get("SETOK_LN_FOLD", "1") != "0" and D % 64 == 0 \
+                and all(b["fc1"][0].shape[0] % 64 == 0 for b in blocks):
+            for b in blocks:
+                b["qkv_ln"] = ops.ln_fold(b["qkv"][0], b["n1"][0], b["n1"][1], b["qkv"][1])
+                b["fc1_ln"] = ops.ln_fold(b["fc1"][0], b["n2"][0], b["n2"][1], b["fc1"][1])
         pix = None
         if self.to_pixels is not None:                                             # rows padded to a multiple of 64 (3 p^2 = 588 at p = 14): aligned GEMM output rows
             n_out = self.to_pixels.out_features
@@ -335,14 +344,22 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
         """detokenizer.py:117-120 on rows (B * Q, D): timm Block = x + proj(attn(norm1 x)); x + fc2(gelu(fc1(norm2 x)))."""
         Q, D, Hh = self.num_mask_token, self.decoder_embed_dim, self.decoder_nheads
         Dh = D // Hh
-        y = None
+        y = st = None
         for b in pk["blocks"]:
-            y = ops.layernorm(h, *b["n1"][:2], b["n1"][2], out=y)
-            qkv = ops.linear(y, *b["qkv"])
+            if "qkv_ln" in b:
+                st = ops.row_stats(h, b["n1"][2], out=st)
+                qkv = ops.linear_ln(h, b["qkv_ln"], st)
+            else:
+                y = ops.layernorm(h, *b["n1"][:2], b["n1"][2], out=y)
+                qkv = ops.linear(y, *b["qkv"])
             o = ops.attention(qkv, Hh, Dh, Dh ** -0.5, seg_len=Q)
             ops.linear(o, *b["proj"], residual=h, out=h)
-            y = ops.layernorm(h, *b["n2"][:2], b["n2"][2], out=y)
-            u = ops.linear(y, *b["fc1"], act=ops.ACT_GELU_ERF)
+            if "fc1_ln" in b:
+                st = ops.row_stats(h, b["n2"][2], out=st)
+                u = ops.linear_ln(h, b["fc1_ln"], st, act=ops.ACT_GELU_ERF)
+            else:
+                y = ops.layernorm(h, *b["n2"][:2], b["n2"][2], out=y)
+                u = ops.linear(y, *b["fc1"], act=ops.ACT_GELU_ERF)
             ops.linear(u, *b["fc2"], residual=h, out=h)
         return ops.layernorm(h, *pk["dec_ln"][:2], pk["dec_ln"][2], out=y)
 
