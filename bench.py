@@ -224,6 +224,43 @@ def load_traffic(applies):
     return d, None
 
 
+def live_traffic(select_layer, log):
+    """The two PMC passes of THIS command on THIS box (round 5; rounds 2-4 replayed the builder's committed passes into the driver's line):
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` as separate sub-processes of `bench.py --steps 2 --warmup 1 --timed-only`
+    (counters cannot be collected inside the timed run; kernel-trace only beside them), reduced by tools/gemm_traffic.py exactly as
+    tools/profile_round.sh does.  Returns (dict, None) or (None, why) — the caller then falls back to the committed file and says so."""
+    import shutil, subprocess, tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 is not on PATH"
+    tmp = tempfile.mkdtemp(prefix="setok_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    dbs = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            t0 = time.perf_counter()
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                                "--steps", "2", "--warmup", "1", "--timed-only", "--select-layer", str(select_layer)],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            found = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not found:
+                return None, f"the {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            dbs[counter] = found[0]
+            log(f"PMC pass {counter}: {time.perf_counter() - t0:.1f} s")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_traffic.py"), dbs["FETCH_SIZE"], dbs["WRITE_SIZE"]],
+                           capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            return None, f"tools/gemm_traffic.py failed: {(r.stderr or r.stdout)[-200:]}"
+        d = json.loads(r.stdout)
+        d["file"] = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this box, inside this run"
+        return d, None
+    except Exception as e:                                            # a profiler that is missing, refuses or hangs must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gemm_class(p):
     return p["kernel"].split(":", 1)[1] if ":" in p["kernel"] else "all"
 
@@ -245,6 +282,7 @@ def main():
                     help="hidden_states index the tower returns: -1 (default) = what the reference's launch scripts pass and its training dataclass "
                          "defaults to (scripts/pretrain_mm_proj.sh:43, scripts/finetune.sh:67, src/train/training_utils.py:25: all 24 layers run); "
                          "-2 = the reference classes' own default (tokenizer.py:18, 23 of 24 layers), reported beside it as `also_select_layer_minus2`")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 PMC sub-runs behind the timed region (≈ 1 min); the committed passes are quoted instead")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs: nothing but warm-up + the timed steps (no clock / power sampling loop, no select_layer = -2 steps, no CPU "
                          "baseline), so that two rocprofv3 passes of the same command see the same launches")
@@ -399,7 +437,21 @@ def main():
     # clock / power under load: rank 0 re-runs the step while polling rocm-smi — only where the step has no collective (a training step's
     # all-reduce would wait for ranks that are not stepping)
     telemetry = gpu_telemetry(step, local) if rank == 0 and not args.timed_only and (world == 1 or trainer is None) else None
-    traffic, traffic_note = load_traffic(args.workload == "cfg2" and args.dtype == "bf16" and B == 256 and args.select_layer == -1)
+    applies = args.workload == "cfg2" and args.dtype == "bf16" and B == 256 and args.select_layer == -1
+    traffic, traffic_note = None, None
+    if rank == 0 and world == 1 and applies and not args.timed_only and not args.no_cpu_baseline and not args.no_live_traffic:
+        traffic, why = live_traffic(args.select_layer, log)           # the default run: measured here, on this box
+        if traffic is None:
+            log(f"live PMC passes unavailable ({why}); falling back to the committed passes")
+            live_note = why
+        else:
+            live_note = None
+    else:
+        live_note = "not collected in this invocation (multi-rank, --timed-only, --no-cpu-baseline or --no-live-traffic)"
+    if traffic is None:
+        traffic, traffic_note = load_traffic(applies)
+        if traffic is not None:
+            traffic["file"] = f"{traffic['file']} (the builder's committed passes; live passes: {live_note})" 
     if rank == 0:
         gname = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
