@@ -86,13 +86,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     partial[(int64_t)blockIdx.y * cols + c] = s;
 }
 
+// Round 5: 64 columns per workgroup, the chunks dealt to four quarter-sums per column (chunk k -> quarter k & 3, each an ascending chain with four
+// loads in flight), combined in the fixed order ((q0 + q1) + (q2 + q3)) [+ out]: deterministic.  One thread walking all (up to 256) chunks of its
+// column took 24 us per call, 38 calls per training step (profiles/r05_bench_cfg4_kernel_stats.csv).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols, float* __restrict__ out,
                                                            int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * cols + c];
-    out[c] = s;
+    __shared__ float q[4][64];
+    const int cl = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        int k = kq;
+        for (; k + 4 < chunks; k += 8) { s0 += partial[(int64_t)k * cols + c]; s1 += partial[(int64_t)(k + 4) * cols + c]; }
+        if (k < chunks) s0 += partial[(int64_t)k * cols + c];
+    }
+    q[kq][cl] = s0 + s1;
+    __syncthreads();
+    if (kq == 0 && c < cols) {
+        const float s = (q[0][cl] + q[1][cl]) + (q[2][cl] + q[3][cl]);
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // ---- LayerNorm backward: one wave per row; the row, its statistics and the three reductions live in registers ---------------------
@@ -449,7 +462,7 @@ extern "C" int setok_colsum(void* stream, int dtype, const void* x, int rows, in
     dim3 grid(cdiv(cols, 256), chunks);
     DISPATCH_T("setok_colsum", (colsum_partial_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, rows, cols, rpc, ws)),
                (colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)x, rows, cols, rpc, ws)));
-    colsum_final_kernel<<<cdiv(cols, 256), 256, 0, s>>>(ws, chunks, cols, out, accumulate);
+    colsum_final_kernel<<<cdiv(cols, 64), 256, 0, s>>>(ws, chunks, cols, out, accumulate);
     SETOK_CHECK_LAUNCH("setok_colsum");
     return SETOK_OK;
 }
@@ -470,8 +483,8 @@ extern "C" int setok_layernorm_bwd(void* stream, int dtype, const void* x, const
     DISPATCH_T("setok_layernorm_bwd",
                (layernorm_bwd_kernel<bf16><<<nb, 256, smem, s>>>((const bf16*)x, (const bf16*)dy, gamma, eps, rows, C, (bf16*)dx, (const bf16*)res, pg, pb)),
                (layernorm_bwd_kernel<float><<<nb, 256, smem, s>>>((const float*)x, (const float*)dy, gamma, eps, rows, C, (float*)dx, (const float*)res, pg, pb)));
-    colsum_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(pg, nb, C, dgamma, accumulate);
-    colsum_final_kernel<<<cdiv(C, 256), 256, 0, s>>>(pb, nb, C, dbeta, accumulate);
+    colsum_final_kernel<<<cdiv(C, 64), 256, 0, s>>>(pg, nb, C, dgamma, accumulate);
+    colsum_final_kernel<<<cdiv(C, 64), 256, 0, s>>>(pb, nb, C, dbeta, accumulate);
     SETOK_CHECK_LAUNCH("setok_layernorm_bwd");
     return SETOK_OK;
 }
