@@ -751,7 +751,8 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 // output element (the results are bit-identical to gemm_persist_kernel's), a different SCHEDULE of the K loop:
 //   * a K-tile is four phases per wave — the quadrants (row half i, column half j) of its 128 x 64 output in the order (0,0) (0,1) (1,1) (1,0) —
 //     each a LOAD slot (fragment reads, one quarter-tile of LDS-DMA requests) and an MFMA slot (16 MFMAs), every slot closed by s_barrier;
-//   * the two wave rows run ONE SLOT APART (waves 4-7 execute one extra barrier first): on every SIMD one wave multiplies while its partner reads
+//   * the two wave rows run ONE SLOT APART (waves 4-7 execute one extra barrier in front of every tile's K loop, waves 0-3 one behind it — per TILE
+//     since round 5, so that both rows reach the epilogue together; PP_RESYNC): on every SIMD one wave multiplies while its partner reads
 //     fragments and stands at the address unit — the matrix pipe never has two claimants, and the lock-step in which gemm_persist_kernel's two
 //     waves of a SIMD both fetch and then both multiply (matrix pipe busy 47 % of a launch) is gone by construction;
 //   * operands arrive in QUARTER tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255 of a stage: 16 KiB = 2 requests per lane, full 128-byte
@@ -1237,7 +1238,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                             // streaming store in SGPR-base form (the builtin falls back to 64-bit per-lane addresses)
                             // (s_nop 1: a VALU write of the data registers of a > 64-bit store needs two wait states behind it on gfx940+ — the compiler's hazard
                             //  recognizer pads its own stores, it cannot know that this statement is one: without the pad the erf-GELU instantiation, which reuses
-                            //  the registers at once, stored the next element's intermediates — r05_dbg2)
+                            //  the registers at once, stored the next element's intermediates — profiles/r05_nt_store_hazard.log)
                             asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
                         } else
 #endif
