@@ -242,7 +242,7 @@ def live_traffic(select_layer, log):
             t0 = time.perf_counter()
             r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                                 "--steps", "2", "--warmup", "1", "--timed-only", "--select-layer", str(select_layer)],
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             found = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not found:
                 return None, f"the {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
