@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 7
+#define SETOK_ABI_VERSION 8
 
 enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
@@ -100,7 +100,12 @@ int64_t setok_encode_workspace_bytes(const setok_ctx* ctx, int B);
  * ASYNCHRONOUS (since ABI 5): no host synchronisation between the stages — the ragged stages are launched at their worst-case
  * size and read the per-image token counts on the device — so with counts_host == NULL the call only enqueues work on `stream` (it can be
  * captured into a hipGraph) and the host reads `counts` whenever it needs shapes.  counts_host != NULL (B ints; total_tokens_host optional) is
- * the convenience form: ONE stream synchronisation at the END of the call fills them. */
+ * the convenience form: ONE host wait at the END of the call fills them.  Since ABI 8 that wait is for the COUNTS only (they are final behind
+ * the clustering stage and are copied to the host there): when the call returns, its remaining launches — the head, about 1 ms of device time at
+ * batch 256 — may still be queued or running, so that the caller's next launches (the projector) queue up behind them and the device never
+ * idles.  `tokens`, `idx_cluster`, `score`, `index_down` and the stage pointers are complete IN STREAM ORDER like the outputs of every other call
+ * of this library: work enqueued on `stream` sees them; a host that reads them directly synchronises the stream first (a blocking hipMemcpy on
+ * the null stream does). */
 int setok_encode(setok_ctx* ctx, void* stream, const void* images, int B, int k, float threshold, const float* noise,
                  const float* token_mask, void* workspace, int64_t workspace_bytes, void* tokens, int32_t* counts,
                  int64_t* idx_cluster, float* score, int64_t* index_down, int32_t* counts_host, int64_t* total_tokens_host,

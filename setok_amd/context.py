@@ -78,7 +78,9 @@ class EncodeContext:
         score (B, N) fp32, index_down (B, N) int64[, stages]).
 
         `setok_encode` itself never waits for the device (the ragged stages read the token counts there); this wrapper reads the B counts
-        ONCE, after everything is queued, because a RaggedTokens needs host-side shapes.  sync=False skips even that: the call only enqueues
+        ONCE, after everything is queued, because a RaggedTokens needs host-side shapes — and waits for THEM only (they are final behind the
+        clustering): the returned tensors are complete in stream order, like the result of any torch operation, while the head's last launches may
+        still be running when the call returns (so the caller's next launches queue up behind them instead of finding the device idle).  sync=False skips even that: the call only enqueues
         work (it can be captured into a graph) and returns (tokens at the worst-case capacity (B * N, D), counts as a DEVICE int32 tensor, idx,
         score, index_down); rows of `tokens` past sum(counts) are unspecified."""
         B, N, dev = images.shape[0], self.N, self.device
@@ -103,6 +105,12 @@ class EncodeContext:
         if token_mask is not None:
             token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
             assert token_mask.numel() == B * N
+        if ws is self._ws.get(B):
+            # the context's own workspace is shared by every call of this batch size: since ABI 8 a call returns while its last launches are
+            # still running, so a call made on ANOTHER stream waits for the previous call's end first (a no-op on the same stream)
+            ev = self.__dict__.get("_ws_free")
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)
         counts_h = (C.c_int32 * B)() if sync else None
         total = C.c_int64(0)
         sx, sg, si = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -111,6 +119,11 @@ class EncodeContext:
                   ws.data_ptr(), ws.numel(), tokens.data_ptr(), counts.data_ptr(), idx.data_ptr(), score.data_ptr(), index_down.data_ptr(),
                   counts_h, C.byref(total) if sync else None, C.byref(sx) if return_stages else None, C.byref(sg) if return_stages else None,
                   C.byref(si) if return_stages else None)
+        if ws is self._ws.get(B):
+            ev = self.__dict__.get("_ws_free")
+            if ev is None:
+                ev = self.__dict__["_ws_free"] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
         if not sync:
             if return_stages:
                 raise ValueError("return_stages needs the host-side counts (sync=True)")

@@ -64,6 +64,7 @@ struct setok_ctx {
     BlockW inner, inter;
     int32_t* counts_pinned = nullptr;
     int counts_cap = 0;
+    hipEvent_t counts_ready = nullptr;            // recorded behind the counts' device-to-host copy (setok_encode's convenience form)
     char err[512];
 };
 
@@ -130,6 +131,7 @@ extern "C" void setok_destroy(setok_ctx* c) {
     if (!c) return;
     for (void* p : c->owned) (void)hipFree(p);
     if (c->counts_pinned) (void)hipHostFree(c->counts_pinned);
+    if (c->counts_ready) (void)hipEventDestroy(c->counts_ready);
     delete c;
 }
 
@@ -421,6 +423,24 @@ extern "C" int setok_encode(setok_ctx* c, void* stream, const void* images, int 
     const int kk = k != 0 ? k : f.min_cluster_num;                                    // `k if k else self.min_cluster_num` (:172)
     RUN(setok_cluster_dpc_knn(st, dt, p.x, B, N, C, kk, thr, f.min_cluster_num, noise, token_mask, idx_cluster, score, index_down, counts, p.dist_ws, p.vec_ws));
     RUN(setok_cluster_sort(st, idx_cluster, counts, B, N, p.perm, p.seg_offsets, p.img_offsets));
+    if (counts_host) {
+        // The token counts are final HERE.  A host that wants the shapes (counts_host != NULL) gets them copied now and waits for THIS copy at the end
+        // of the call, not for the stream: the head's launches (~1.2 ms of device time at batch 256) are then still queued or running, and whatever
+        // the host enqueues next — the projector — lands behind them with the device never idle.  Round 5: waiting for the whole stream left the
+        // device idle for 220-300 us per call (wake-up of the blocked host thread + the way back up into the caller + its next launch).
+        if (c->counts_cap < B) {
+            if (c->counts_pinned) (void)hipHostFree(c->counts_pinned);
+            c->counts_pinned = nullptr; c->counts_cap = 0;
+            if (hipHostMalloc((void**)&c->counts_pinned, (size_t)B * 4, hipHostMallocDefault) != hipSuccess) return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: pinned allocation failed");
+            c->counts_cap = B;
+        }
+        if (!c->counts_ready && hipEventCreateWithFlags(&c->counts_ready, hipEventDisableTiming) != hipSuccess) {
+            c->counts_ready = nullptr;
+            return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: event creation failed");
+        }
+        if (hipMemcpyAsync(c->counts_pinned, counts, (size_t)B * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(c->counts_ready, s) != hipSuccess)
+            return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: reading the token counts failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     // No host synchronisation between the stages: the ragged stages are launched at their worst-case size — B * N cluster
     // segments, B * N cluster-token rows — and take the actual numbers from the device: the segment offsets past the last cluster are empty
     // segments (setok_cluster_sort), the GEMMs / LayerNorms of the inter encoder and `out` read the row count sum(L_i) = img_offsets[B] and skip
@@ -442,14 +462,10 @@ extern "C" int setok_encode(setok_ctx* c, void* stream, const void* images, int 
     if (stage_inter) *stage_inter = inter;
     RUN(lin(st, dt, inter, C, W("out.weight"), (const float*)W("out.bias"), nullptr, tokens, rN, f.token_feat_dim, SETOK_ACT_NONE, total_dev));   // :180
     if (!counts_host) return SETOK_OK;                                                // fully asynchronous: the caller reads `counts` when it wants shapes
-    // convenience for hosts that want the shapes right away: ONE synchronisation, at the END of the call (every launch is already queued)
-    if (c->counts_cap < B) {
-        if (c->counts_pinned) (void)hipHostFree(c->counts_pinned);
-        c->counts_pinned = nullptr; c->counts_cap = 0;
-        if (hipHostMalloc((void**)&c->counts_pinned, (size_t)B * 4, hipHostMallocDefault) != hipSuccess) return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: pinned allocation failed");
-        c->counts_cap = B;
-    }
-    if (hipMemcpyAsync(c->counts_pinned, counts, (size_t)B * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    // convenience for hosts that want the shapes right away: ONE wait, at the END of the call (every launch is already queued), for the copy of the
+    // counts issued behind the clustering — NOT for the launches behind it: `tokens` and the other outputs are complete in stream order
+    static const bool wait_stream = [] { const char* e = getenv("SETOK_ENCODE_WAIT"); return e && e[0] == 's'; }();   // SETOK_ENCODE_WAIT=stream: rounds 3-4 (A/B runs)
+    if ((wait_stream ? hipStreamSynchronize(s) : hipEventSynchronize(c->counts_ready)) != hipSuccess)
         return ctx_fail(c, SETOK_ELAUNCH, "setok_encode: reading the token counts failed: %s", hipGetErrorString(hipGetLastError()));
     int64_t total = 0;
     for (int b = 0; b < B; ++b) { counts_host[b] = c->counts_pinned[b]; total += counts_host[b]; }

@@ -45,6 +45,8 @@ struct PArgs {
     const float* ln_stats;       // LNK variant: per row of A 8 floats {row fragment (4 dwords), rstd, mean, 0, 0} (setok_row_stats): the LayerNorm folded into this GEMM
     const float* ln_colsum;      //   per column 4 dwords: the column fragment of c[n] = sum_k W'[n][k] and b'[n] = b[n] + sum_k W[n][k] beta[k] (setok_ln_fold)
     const int32_t* m_dev;        // optional device-side row count (<= M): tiles beyond it are never visited (setok_linear_dev)
+    int rem_rows;                // ping-pong kernel only: rows [M, M + rem_rows) — the remainder behind the whole 256-row tiles — are finished by the same launch
+    int rem_tiles;               //   as small tiles (gemm_tail_tile), one per workgroup 0 .. rem_tiles - 1, after the workgroup's last 256 x 256 tile
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -497,18 +499,19 @@ __host__ __device__ constexpr int tail_lds(int ttm, int ttn, int ns) { return ns
 // the workgroups, each streaming 3/4 / 1/2 of the bytes: these launches are bound by the latency of one workgroup's K loop); NS: pipeline stages
 // (8, or 4 = 66 KiB so that TWO workgroups fit a CU when a launch has more tiles than CUs).  The arithmetic per output element does not depend on
 // any of them.
-template <int ACT, bool LNK = false, int TTM = 64, int TTN = 64, int NS = TNS>
-__global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
+// One tile, by the four waves (threads 0-255) of a workgroup: the whole of gemm_tail_kernel, and the remainder rows of a ping-pong launch (there the
+// second wave row has ended: s_barrier counts the surviving waves only).
+template <int ACT, bool LNK, int TTM, int TTN, int NS>
+__device__ __forceinline__ void gemm_tail_tile(const PArgs& g, const int tile, char* smem) {
     constexpr int NI = TTM / 32, NJ = TTN / 32;             // 16 x 16 MFMA tiles per wave (wave = TTM / 2 rows x TTN / 2 columns)
     constexpr int LPT = NI + NJ;                            // LDS-DMA loads per lane per K-tile: TTM / 32 of A, TTN / 32 of W
     constexpr int STG = tail_stage(TTM, TTN);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int nk = g.K / TK;
-    const int m0 = (blockIdx.x / g.tilesN) * TTM, n0 = (blockIdx.x % g.tilesN) * TTN;
+    const int m0 = (tile / g.tilesN) * TTM, n0 = (tile % g.tilesN) * TTN;
     const int Mrt = g.m_dev ? min(g.M, __builtin_amdgcn_readfirstlane(*g.m_dev)) : g.M;
     if (m0 >= Mrt) return;                                  // a ragged stage's tiles beyond its device-side row count (before any barrier)
     float* sbias = reinterpret_cast<float*>(smem + NS * STG);
@@ -697,6 +700,12 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     }
 }
 
+template <int ACT, bool LNK = false, int TTM = 64, int TTN = 64, int NS = TNS>
+__global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_tail_tile<ACT, LNK, TTM, TTN, NS>(g, blockIdx.x, smem);
+}
+
 // Shape of the small-tile launch for a problem of M x N outputs (host side): how many workgroups the default 64 x 64 tiles give against the CUs.
 // SETOK_GEMM_SMALL_SHAPE=0 keeps the default everywhere (A/B runs).
 struct TailShape { int ttm, ttn, ns; };
@@ -803,6 +812,9 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #define PP_POL_C PP_POLSTR(PP_PC)
 #ifndef PP_RESYNC
 #define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
+#endif
+#ifndef PP_MERGE_REM
+#define PP_MERGE_REM 1      // 1: a launch finishes its remainder rows itself (see the end of gemm_pp_body); 0: they are a launch of the small-tile kernel (rounds 3-4)
 #endif
 #ifndef PP_NO_EDGE
 #define PP_NO_EDGE 1        // 1: the host hands this kernel whole 256-row tiles only (the remainder rows go to the small-tile kernel, a device-side M to gemm_persist_kernel)
@@ -1272,6 +1284,28 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #if !PP_RESYNC
     if (GRP == 0) bar();                                    // matches the second row's last barrier
 #endif
+#if PP_MERGE_REM
+    // ---- the remainder rows (round 5) ---------------------------------------------------------------------------------------------------------------
+    // M = 65792 = 257 tile rows: 257 * N / 256 tiles never divide by 256 CUs, so the last tile row was a launch of its own on the small-tile kernel
+    // (8-9 us + the ~5 us between two dependent dispatches, four times per ViT layer).  Here the first wave row of workgroups 0 .. rem_tiles - 1 runs
+    // that kernel's tile function behind its last 256 x 256 tile — same arithmetic, same bits; the second wave row has ended by then or ends without
+    // another barrier (a barrier counts the surviving waves only).
+    if constexpr (GRP == 0 && (LNK || RESK)) {
+        if (g.rem_rows > 0) {
+            bar();                                          // this row's four waves are out of their epilogues: wave 0's staging rows hold the small tile's bias rows
+            if ((int)blockIdx.x < g.rem_tiles) {
+                constexpr int RT = LNK ? 64 : 32;           // the shapes tail_shape_for picks for 256 rows x 3072 / 4096 columns and x 1024 columns
+                PArgs t = g;
+                t.A = g.A + (int64_t)g.M * g.lda;
+                t.C = g.C + (int64_t)g.M * g.ldc;
+                if constexpr (RESK) t.res = g.res + (int64_t)g.M * g.ldc;
+                if constexpr (LNK) t.ln_stats = g.ln_stats + 8 * (int64_t)g.M;
+                t.M = g.rem_rows; t.tilesM = (g.rem_rows + RT - 1) / RT; t.tilesN = g.N / RT; t.m_dev = nullptr;
+                gemm_tail_tile<ACT, LNK, RT, RT, TNS>(t, blockIdx.x, smem);
+            }
+        }
+    }
+#endif
 }
 
 template <int ACT, bool LNK, bool RESK = false>
@@ -1284,6 +1318,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PArgs g) {
 static bool pp_enabled() {
     static const bool on = [] { const char* e = getenv("SETOK_GEMM_PP"); return !(e && e[0] == '0'); }();
     return on;
+}
+
+// Does this main launch go to the ping-pong kernel?
+static bool pp_takes(const PArgs& g) {
+    static const bool pp_res = [] { const char* e = getenv("SETOK_GEMM_PP_RES"); return !(e && e[0] == '0'); }();     // A/B: residual launches on the old kernel
+    const bool res = g.res && !(g.dbg & 2);
+    return (!res || pp_res) && !g.Cf && g.N % 256 == 0 && g.K >= 128 && (PP_TIMING_ON || !g.tim) && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev));
 }
 
 int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0, hipEvent_t e1) {
@@ -1302,8 +1343,7 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
     const int grid = tiles < n_cu ? tiles : n_cu;
     const bool res = g.res && !(g.dbg & 2);
     const dim3 gr(grid), bl(512);
-    static const bool pp_res = [] { const char* e = getenv("SETOK_GEMM_PP_RES"); return !(e && e[0] == '0'); }();     // A/B: residual launches on the old kernel
-    if ((!res || pp_res) && !g.Cf && g.N % 256 == 0 && g.K >= 128 && (PP_TIMING_ON || !g.tim) && pp_enabled() && (!PP_NO_EDGE || (g.M % TM == 0 && !g.m_dev))) {   // the ping-pong schedule (whole tiles)
+    if (pp_takes(g)) {                                      // the ping-pong schedule (whole tiles)
         static SetokDeviceOnce once_pp;
         if (!once_pp.run([] {
                 bool ok = true;
@@ -1397,7 +1437,18 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     }
     // the profiler's timestamps ride on the dispatches themselves: start of the first launch, end of the last (common.h)
     const bool has_main = (tilesM - p) > 0;
-    int rc = has_main ? launch_main(s, g, act, ncu, setok_prof_start_event(), p == 0 ? setok_prof_stop_event() : nullptr) : SETOK_OK;
+    // The remainder rows inside the main launch (end of gemm_pp_body): when the main launch is a ping-pong one with a folded LayerNorm or a residual
+    // and the remainder's small tiles — of the shape tail_shape_for would pick — are no more than its workgroups.  SETOK_GEMM_MERGE_REM=0: a launch
+    // of their own as before (A/B runs; the results are the same bits either way).
+    static const bool merge_rem = [] { const char* e = getenv("SETOK_GEMM_MERGE_REM"); return !(e && e[0] == '0'); }();
+    bool merged = false;
+    if (PP_MERGE_REM && merge_rem && has_main && p > 0 && pp_takes(g) && (ln_stats || (res && !(dbg & 2)))) {
+        const int rem = M - tm_main * TM, want = ln_stats ? 64 : 32;
+        const TailShape sh = tail_shape_for(rem, N, ncu);
+        const int rem_tiles = cdiv(rem, want) * (N / want), grid = tm_main * tilesN < ncu ? tm_main * tilesN : ncu;
+        if (sh.ttm == want && sh.ttn == want && sh.ns == TNS && rem_tiles <= grid) { g.rem_rows = rem; g.rem_tiles = rem_tiles; merged = true; }
+    }
+    int rc = has_main ? launch_main(s, g, act, ncu, setok_prof_start_event(), p == 0 || merged ? setok_prof_stop_event() : nullptr) : SETOK_OK;
     if (timing && tim) {
         unsigned long long h[256 * 4];
         if (hipMemcpy(h, tim, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1422,7 +1473,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 #endif
         }
     }
-    if (rc != SETOK_OK || p == 0) return rc;
+    if (rc != SETOK_OK || p == 0 || merged) return rc;
     const int m_off = tm_main * TM;
     const TailShape sh = tail_shape_for(M - m_off, N, ncu);          // the remainder rows: a launch of its own, far from filling the chip
     PArgs t{A + (int64_t)m_off * lda, W, bias, res ? res + (int64_t)m_off * ldc : nullptr, C + (int64_t)m_off * ldc,

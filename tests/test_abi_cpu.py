@@ -44,7 +44,7 @@ def test_ctypes_table_matches_header(lib):
 
 def test_abi_version_and_error_plumbing(lib):
     l = lib.load()
-    assert l.setok_abi_version() == 7
+    assert l.setok_abi_version() == 8
     # argument validation happens on the host before any launch: usable without a GPU
     rc = l.setok_linear(None, 0, 0, None, 0, None, None, None, None, 0, 1, 1, 16, 0, 1, 0, 0, 0)
     assert rc == -1 and b"null operand" in l.setok_last_error()
