@@ -47,6 +47,7 @@ struct PArgs {
     const int32_t* m_dev;        // optional device-side row count (<= M): tiles beyond it are never visited (setok_linear_dev)
     int rem_rows;                // ping-pong kernel only: rows [M, M + rem_rows) — the remainder behind the whole 256-row tiles — are finished by the same launch
     int rem_tiles;               //   as small tiles (gemm_tail_tile), one per workgroup 0 .. rem_tiles - 1, after the workgroup's last 256 x 256 tile
+    int rem_shape;               //   64: 64 x 64 tiles, 32: 32 x 32 tiles (what tail_shape_for picks for the remainder as a launch of its own)
 };
 
 __device__ inline void s_barrier_lgkm() {         // LDS ops of this wave retired, then the workgroup barrier
@@ -1290,18 +1291,19 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     // (8-9 us + the ~5 us between two dependent dispatches, four times per ViT layer).  Here the first wave row of workgroups 0 .. rem_tiles - 1 runs
     // that kernel's tile function behind its last 256 x 256 tile — same arithmetic, same bits; the second wave row has ended by then or ends without
     // another barrier (a barrier counts the surviving waves only).
-    if constexpr (GRP == 0 && (LNK || RESK)) {
+    if constexpr (GRP == 0) {
         if (g.rem_rows > 0) {
             bar();                                          // this row's four waves are out of their epilogues: wave 0's staging rows hold the small tile's bias rows
             if ((int)blockIdx.x < g.rem_tiles) {
-                constexpr int RT = LNK ? 64 : 32;           // the shapes tail_shape_for picks for 256 rows x 3072 / 4096 columns and x 1024 columns
+                const int RT = g.rem_shape;                 // 64 (256 rows x 3072 / 4096 columns) or 32 (x 1024 columns; a few rows): tail_shape_for's choice
                 PArgs t = g;
                 t.A = g.A + (int64_t)g.M * g.lda;
                 t.C = g.C + (int64_t)g.M * g.ldc;
                 if constexpr (RESK) t.res = g.res + (int64_t)g.M * g.ldc;
                 if constexpr (LNK) t.ln_stats = g.ln_stats + 8 * (int64_t)g.M;
                 t.M = g.rem_rows; t.tilesM = (g.rem_rows + RT - 1) / RT; t.tilesN = g.N / RT; t.m_dev = nullptr;
-                gemm_tail_tile<ACT, LNK, RT, RT, TNS>(t, blockIdx.x, smem);
+                if (RT == 64) gemm_tail_tile<ACT, LNK, 64, 64, TNS>(t, blockIdx.x, smem);
+                else gemm_tail_tile<ACT, LNK, 32, 32, TNS>(t, blockIdx.x, smem);
             }
         }
     }
@@ -1437,16 +1439,16 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     }
     // the profiler's timestamps ride on the dispatches themselves: start of the first launch, end of the last (common.h)
     const bool has_main = (tilesM - p) > 0;
-    // The remainder rows inside the main launch (end of gemm_pp_body): when the main launch is a ping-pong one with a folded LayerNorm or a residual
-    // and the remainder's small tiles — of the shape tail_shape_for would pick — are no more than its workgroups.  SETOK_GEMM_MERGE_REM=0: a launch
+    // The remainder rows inside the main launch (end of gemm_pp_body): when the main launch is a ping-pong one and the remainder's small tiles — of the
+    // shape tail_shape_for would pick, 64 x 64 or 32 x 32 — are no more than its workgroups.  SETOK_GEMM_MERGE_REM=0: a launch
     // of their own as before (A/B runs; the results are the same bits either way).
     static const bool merge_rem = [] { const char* e = getenv("SETOK_GEMM_MERGE_REM"); return !(e && e[0] == '0'); }();
     bool merged = false;
-    if (PP_MERGE_REM && merge_rem && has_main && p > 0 && pp_takes(g) && (ln_stats || (res && !(dbg & 2)))) {
-        const int rem = M - tm_main * TM, want = ln_stats ? 64 : 32;
+    if (PP_MERGE_REM && merge_rem && has_main && p > 0 && pp_takes(g)) {
+        const int rem = M - tm_main * TM;
         const TailShape sh = tail_shape_for(rem, N, ncu);
-        const int rem_tiles = cdiv(rem, want) * (N / want), grid = tm_main * tilesN < ncu ? tm_main * tilesN : ncu;
-        if (sh.ttm == want && sh.ttn == want && sh.ns == TNS && rem_tiles <= grid) { g.rem_rows = rem; g.rem_tiles = rem_tiles; merged = true; }
+        const int rem_tiles = cdiv(rem, sh.ttm) * (N / sh.ttn), grid = tm_main * tilesN < ncu ? tm_main * tilesN : ncu;
+        if (sh.ttm == sh.ttn && sh.ns == TNS && rem_tiles <= grid) { g.rem_rows = rem; g.rem_tiles = rem_tiles; g.rem_shape = sh.ttm; merged = true; }
     }
     int rc = has_main ? launch_main(s, g, act, ncu, setok_prof_start_event(), p == 0 || merged ? setok_prof_stop_event() : nullptr) : SETOK_OK;
     if (timing && tim) {
