@@ -1314,7 +1314,17 @@ template <int ACT, bool LNK, bool RESK = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(PArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef PP_TIMING           // the constant-rate (100 MHz) clock every workgroup of the chip reads the same: when did this workgroup start, and when did its first wave row end
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (wave < 4) gemm_pp_body<ACT, LNK, RESK, 0>(g, smem); else gemm_pp_body<ACT, LNK, RESK, 1>(g, smem);
+#ifdef PP_TIMING
+    if (g.tim && (threadIdx.x == 0 || threadIdx.x == 256)) {
+        unsigned long long* f = g.tim + 256 * 4 + 256 * 2 * 20 + blockIdx.x * 3;
+        if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f[0] = rt0; f[1] = __builtin_amdgcn_s_memrealtime(); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f[2] = __builtin_amdgcn_s_memrealtime(); }
+    }
+#endif
 }
 
 static bool pp_enabled() {
@@ -1429,7 +1439,7 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     const int tm_main = tilesM - p;
     static const bool timing = [] { const char* e = getenv("SETOK_GEMM_TIMING"); return e && e[0] == '1'; }();
     static unsigned long long* tim = nullptr;
-    if (timing && !tim) { if (hipMalloc(&tim, (256 * 4 + 256 * 2 * 20) * 8) != hipSuccess) tim = nullptr; else (void)hipMemset(tim, 0, (256 * 4 + 256 * 2 * 20) * 8); }
+    if (timing && !tim) { if (hipMalloc(&tim, (256 * 4 + 256 * 2 * 20 + 256 * 3) * 8) != hipSuccess) tim = nullptr; else (void)hipMemset(tim, 0, (256 * 4 + 256 * 2 * 20 + 256 * 3) * 8); }
     PArgs g{A, W, bias, res, C, lda, ldc, (tilesM - p) * TM < M ? (tilesM - p) * TM : M, N, K, tilesM - p, tilesN, dbg, timing ? tim : nullptr, nullptr, nullptr, 0, 0, 0, 1,
             ln_stats, ln_colsum, m_dev};
     if (!bias || ln_stats) {
@@ -1460,6 +1470,28 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
             fprintf(stderr, "[gemm timing] M=%d N=%d K=%d tiles/block=%.2f  per tile: main %.0f cyc (vmcnt waits %.0f, barrier waits %.0f), epilogue %.0f cyc\n",
                     M, N, K, r / nb, a / r, c / r, bar / r, b / r);
 #ifdef PP_TIMING
+            {
+                static unsigned long long hr[256 * 3];
+                if (hipMemcpy(hr, tim + 256 * 4 + 256 * 2 * 20, sizeof(hr), hipMemcpyDeviceToHost) == hipSuccess) {
+                    unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0; double es = 0;
+                    for (int i = 0; i < nb; ++i) {
+                        const unsigned long long st = hr[i * 3], en = hr[i * 3 + 1] > hr[i * 3 + 2] ? hr[i * 3 + 1] : hr[i * 3 + 2];
+                        s0 = st < s0 ? st : s0; s1 = st > s1 ? st : s1; e0 = en < e0 ? en : e0; e1 = en > e1 ? en : e1; es += (double)en;
+                    }
+                    {
+                        double xs[8] = {0}, xe[8] = {0}, xl[8] = {0}; int xn[8] = {0};
+                        for (int i = 0; i < nb; ++i) {
+                            const unsigned long long en = hr[i * 3 + 1] > hr[i * 3 + 2] ? hr[i * 3 + 1] : hr[i * 3 + 2];
+                            xs[i & 7] += (double)(hr[i * 3] - s0); xe[i & 7] += (double)(en - s0); xn[i & 7]++; if ((double)(en - s0) > xl[i & 7]) xl[i & 7] = (double)(en - s0);
+                        }
+                        fprintf(stderr, "[gemm timing span] per XCD (workgroup & 7), mean start / mean end / last end after the first start:");
+                        for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, "  %d: %.0f / %.0f / %.0f", x, xs[x] / xn[x], xe[x] / xn[x], xl[x]);
+                        fprintf(stderr, "\n");
+                    }
+                    fprintf(stderr, "[gemm timing span] %d workgroups (100 MHz ticks = 10 ns): first start -> last end %llu; starts spread over %llu; ends spread over %llu (mean end %.0f before the last)\n",
+                            nb, e1 - s0, s1 - s0, e1 - e0, (double)e1 - es / nb);
+                }
+            }
             static unsigned long long hf[256 * 2 * 20];
             if (hipMemcpy(hf, tim + 256 * 4, sizeof(hf), hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int row = 0; row < 2; ++row) {

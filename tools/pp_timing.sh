@@ -3,8 +3,8 @@
 #   bash tools/build_variant.sh tim gemm_persist.hip -DPP_TIMING
 # then on the GPU box: bash tools/pp_timing.sh   (prints the LAST launch of each case: K loop / accumulator start / epilogue, cycles per tile)
 export SETOK_GEMM_TIMING=1 SETOK_HIP_LIB=setok_amd/libsetok_hip_tim.so
-python tools/bench_ln_gemm.py 0.25 2>&1 >/dev/null | awk '/^--- /{name=$0} /gemm timing\]/{last[name]=$0} /gemm timing [a-z]*\] wave row 0/{last[name]=last[name] "\n   " $0} /gemm timing [a-z]*\] wave row 1/{last[name]=last[name] "\n   " $0} END{for (n in last) print n "\n   " last[n]}'
-python - <<'PY' 2>&1 | awk '/^--- /{name=$0} /gemm timing\]/{last[name]=$0} /gemm timing [a-z]*\] wave row 0/{last[name]=last[name] "\n   " $0} /gemm timing [a-z]*\] wave row 1/{last[name]=last[name] "\n   " $0} END{for (n in last) print n "\n   " last[n]}'
+python tools/bench_ln_gemm.py 0.25 2>&1 >/dev/null | awk '/^--- /{name=$0} /gemm timing\]/{last[name]=$0} /gemm timing [a-z]*\] wave row 0/{last[name]=last[name] "\n   " $0} /gemm timing [a-z]*\] wave row 1/{last[name]=last[name] "\n   " $0}  /gemm timing span/{last[name]=last[name] "\n   " $0} END{for (n in last) print n "\n   " last[n]}'
+python - <<'PY' 2>&1 | awk '/^--- /{name=$0} /gemm timing\]/{last[name]=$0} /gemm timing [a-z]*\] wave row 0/{last[name]=last[name] "\n   " $0} /gemm timing [a-z]*\] wave row 1/{last[name]=last[name] "\n   " $0}  /gemm timing span/{last[name]=last[name] "\n   " $0} END{for (n in last) print n "\n   " last[n]}'
 import sys, torch
 sys.path.insert(0, ".")
 from setok_amd import ops
