@@ -33,11 +33,8 @@ __device__ inline bf16x8 pack8s(const float* p) {
 
 // ---- segments of more than 32 rows (the inter encoder: an image's L_i cluster tokens): one workgroup per (segment, head); query and
 //      key tiles are aligned to the segment's first row, so a segment's arithmetic never depends on where it sits in the batch ----------
-__global__ __launch_bounds__(256) void attn_seg_big_kernel(const bf16* __restrict__ qkv, const int32_t* __restrict__ seg_offsets,
-                                                           bf16* __restrict__ out, int H, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) float Sp[4][16 * 64];                 // the waves' partial S^T tiles, [reg][lane]
-    __shared__ __attribute__((aligned(16))) char Vs[4][32 * VROW];                // wave-private V slices of the current key tile
-    const int s = blockIdx.x, h = blockIdx.y;
+__device__ __forceinline__ void attn_seg_big_segment(const bf16* __restrict__ qkv, const int32_t* __restrict__ seg_offsets, bf16* __restrict__ out, int H,
+                                                     float scale_log2e, const int s, const int h, float (*Sp)[16 * 64], char (*Vs)[32 * VROW]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = seg_offsets[s];
@@ -154,10 +151,36 @@ __global__ __launch_bounds__(256) void attn_seg_big_kernel(const bf16* __restric
     }
 }
 
+// SPW = 1: one workgroup per (segment, head) — the inter encoder's B segments.  SPW = 64: the workgroup looks at 64 consecutive segment lengths with ONE
+// coalesced load per wave and runs the (rare) long ones among them — the inner encoder's worst-case launch: B * N segments, ~8 % of them not empty and
+// hardly any longer than 32 rows; as one workgroup per segment that was 131 072 workgroups that load two words and exit, 56 us per call at batch 256.
+template <int SPW>
+__global__ __launch_bounds__(256) void attn_seg_big_kernel(const bf16* __restrict__ qkv, const int32_t* __restrict__ seg_offsets, int n_segs,
+                                                           bf16* __restrict__ out, int H, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) float Sp[4][16 * 64];                 // the waves' partial S^T tiles, [reg][lane]
+    __shared__ __attribute__((aligned(16))) char Vs[4][32 * VROW];                // wave-private V slices of the current key tile
+    if constexpr (SPW == 1) {
+        attn_seg_big_segment(qkv, seg_offsets, out, H, scale_log2e, blockIdx.x, blockIdx.y, Sp, Vs);
+    } else {
+        static_assert(SPW == 64, "one lane per segment length");
+        const int sl = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int nl = sl < n_segs ? seg_offsets[sl + 1] - seg_offsets[sl] : 0;
+        unsigned long long m = __ballot(nl > 32);                                 // (the same mask in all four waves: uniform control flow around the barriers)
+        while (m) {
+            const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            m &= m - 1;
+            attn_seg_big_segment(qkv, seg_offsets, out, H, scale_log2e, blockIdx.x * 64 + b, blockIdx.y, Sp, Vs);
+            __syncthreads();                                                      // the next segment reuses Sp / Vs
+        }
+    }
+}
+
 // ---- segments of at most 32 rows (the inner encoder's clusters: 7 tokens on average, 3 at 336^2): ONE WAVE per (segment, head), four
 //      independent waves per workgroup, no barrier anywhere.  The wave runs the whole 512-dim contraction of the single 32 x 32 score tile
 //      (32 MFMAs, in the same dim order and with the same four-way grouping as the big kernel's LDS sum), one softmax, and the PV product
 //      in four 128-dim passes through its private 8 KiB of LDS.
+// (164 registers = three waves per SIMD.  Asked to fit four / five — amdgpu_waves_per_eu, 106 / 102 registers, no spills — the kernel is 2 % / 8 % SLOWER inside
+//  the step: it is not short of waves; its 64 fragment loads per task touch 32 lines of 128 bytes each for 32 used bytes per line.)
 __global__ __launch_bounds__(256) void attn_seg_small_kernel(const bf16* __restrict__ qkv, const int32_t* __restrict__ seg_offsets, int n_segs,
                                                              bf16* __restrict__ out, int H, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char Vs[4][32 * VROW];
@@ -260,8 +283,10 @@ int setok_attention_seg_bf16(hipStream_t s, const bf16* qkv, const int32_t* seg_
     if (Dh != SD || !seg_offsets || n_segs <= 0 || rows <= 0) return SETOK_EUNSUPPORTED;
     // every segment belongs to exactly one of the two kernels (n <= 32 / n > 32); each exits at once on the other's segments
     attn_seg_small_kernel<<<dim3(cdiv(n_segs, 4), H), 256, 0, s>>>(qkv, seg_offsets, n_segs, out, H, scale * 1.44269504088896340736f);
-    if (max_len > 32)
-        attn_seg_big_kernel<<<dim3(n_segs, H), 256, 0, s>>>(qkv, seg_offsets, out, H, scale * 1.44269504088896340736f);
+    if (max_len > 32) {
+        if (n_segs > 2048) attn_seg_big_kernel<64><<<dim3(cdiv(n_segs, 64), H), 256, 0, s>>>(qkv, seg_offsets, n_segs, out, H, scale * 1.44269504088896340736f);
+        else attn_seg_big_kernel<1><<<dim3(n_segs, H), 256, 0, s>>>(qkv, seg_offsets, n_segs, out, H, scale * 1.44269504088896340736f);
+    }
     SETOK_CHECK_LAUNCH("setok_attention(segments bf16)");
     return SETOK_OK;
 }

@@ -32,3 +32,11 @@ print(f"{len(cp)} blit dispatches in the step; their neighbours:")
 nb = collections.Counter((step[i - 1][0] if i else "-", step[i][0], step[i + 1][0] if i + 1 < len(step) else "-") for i in cp)
 for k, v in nb.most_common(20):
     print(f"  {v:4d} x  {k[0]}  |  {k[1]}  |  {k[2]}")
+# the head of the step (everything behind the tower): one line per dispatch, start relative to the first, duration, gap in front
+hs = [i for i, r in enumerate(step) if "select_add_pos" in r[0]]
+if hs:
+    print("dispatches behind the tower (start us, duration us, idle in front us, kernel):")
+    t0 = step[hs[-1]][1]; prev_end = step[hs[-1] - 1][2] if hs[-1] else t0
+    for n, s_, e_ in step[hs[-1]:]:
+        print(f"  {(s_ - t0) / 1e3:9.1f} {(e_ - s_) / 1e3:8.1f} {(s_ - prev_end) / 1e3:7.1f}  {n}")
+        prev_end = max(prev_end, e_)
