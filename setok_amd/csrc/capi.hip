@@ -101,6 +101,19 @@ namespace {
 constexpr int PROF_RING = 8192;
 int32_t* g_prof_ring = nullptr;
 int g_prof_ring_used = 0;
+// Launches that read the SAME device word in CONSECUTIVE profiler records on one stream (the six GEMMs of the inter encoder and `out` all read sum(L_i))
+// share one copy of it: the word cannot have changed unless something in between writes row counts — setok_cluster_sort, the only producer in this
+// library, says so (setok_prof_rows_changed), and any other record in between (another GEMM, a clustering call) ends the sharing as well.  Round 5: the copies were seven blit
+// dispatches per step, ~9 us each with the idle time either side, inside the timed region.
+const int32_t* g_rows_last_dev = nullptr;
+int32_t* g_rows_last_host = nullptr;
+hipStream_t g_rows_last_stream = nullptr;
+int g_rows_last_index = -2;
+}
+void setok_prof_rows_changed() {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_rows_last_dev = nullptr;
 }
 void setok_prof_rows(hipStream_t s, int index, const int32_t* rows_dev, int rows_full, double bytes_fixed) {
     if (index < 0 || !rows_dev || rows_full <= 0) return;
@@ -109,9 +122,15 @@ void setok_prof_rows(hipStream_t s, int index, const int32_t* rows_dev, int rows
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (index >= (int)g_prof.size()) return;
     if (capturing || !g_prof_ring || g_prof_ring_used >= PROF_RING) { g_prof[index].kind = -1; return; }
-    int32_t* h = g_prof_ring + g_prof_ring_used++;
-    *h = rows_full;
-    (void)hipMemcpyAsync(h, rows_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    int32_t* h;
+    if (rows_dev == g_rows_last_dev && s == g_rows_last_stream && g_rows_last_host && index == g_rows_last_index + 1) h = g_rows_last_host;      // the same word, nothing in between that writes it
+    else {
+        h = g_prof_ring + g_prof_ring_used++;
+        *h = rows_full;
+        (void)hipMemcpyAsync(h, rows_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        g_rows_last_dev = rows_dev; g_rows_last_host = h; g_rows_last_stream = s;
+    }
+    g_rows_last_index = index;
     g_prof[index].rows_host = h; g_prof[index].rows_full = rows_full; g_prof[index].bytes_fixed = bytes_fixed;
 }
 
@@ -124,6 +143,7 @@ extern "C" int setok_profile_start(void) {
         (void)hipGetLastError();
     }
     g_prof_ring_used = 0;
+    g_rows_last_dev = nullptr; g_rows_last_host = nullptr; g_rows_last_index = -2;
     g_prof_on = 1;
     return SETOK_OK;
 }

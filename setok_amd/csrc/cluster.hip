@@ -1428,6 +1428,7 @@ extern "C" int setok_cluster_sort(void* stream, const int64_t* idx_cluster, cons
     hipStream_t s = (hipStream_t)stream;
     prefix_counts_kernel<<<1, 64, 0, s>>>(counts, img_offsets, B);
     sort_kernel<<<B, 256, 0, s>>>(idx_cluster, counts, img_offsets, B, N, perm, seg_offsets);
+    setok_prof_rows_changed();                                 // img_offsets[B] is the device-side row count of the ragged stages behind this call
     SETOK_CHECK_LAUNCH("setok_cluster_sort");
     return SETOK_OK;
 }

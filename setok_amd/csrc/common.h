@@ -39,6 +39,7 @@ bool setok_prof_on();
 int setok_prof_begin(hipStream_t s, int kind, int cls, double work, double bytes, bool attach);    // cls: act | residual << 2 | layernorm << 3; returns the record's index
 void setok_prof_end(hipStream_t s, int index);
 void setok_prof_rows(hipStream_t s, int index, const int32_t* rows_dev, int rows_full, double bytes_fixed);   // the launch processes *rows_dev of the rows_full its record was priced for
+void setok_prof_rows_changed();                        // a kernel that writes device-side row counts was launched: the profiler re-reads them for the next launch
 // A scope opened with attach = true does not put marker events on the stream: its first launch takes setok_prof_start_event() and its last
 // setok_prof_stop_event() through hipExtLaunchKernelGGL, so the timestamps are the dispatches' own (start of the first kernel, end of the
 // last) and no barrier packet sits between the launches — marker events around each of the ~110 GEMM calls of a cfg2 step cost 0.55 ms of a
