@@ -1457,8 +1457,11 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
     if (PP_MERGE_REM && merge_rem && has_main && p > 0 && pp_takes(g)) {
         const int rem = M - tm_main * TM;
         const TailShape sh = tail_shape_for(rem, N, ncu);
-        const int rem_tiles = cdiv(rem, sh.ttm) * (N / sh.ttn), grid = tm_main * tilesN < ncu ? tm_main * tilesN : ncu;
-        if (sh.ttm == sh.ttn && sh.ns == TNS && rem_tiles <= grid) { g.rem_rows = rem; g.rem_tiles = rem_tiles; g.rem_shape = sh.ttm; merged = true; }
+        const int grid = tm_main * tilesN < ncu ? tm_main * tilesN : ncu;
+        int shape = sh.ttm == sh.ttn && sh.ns == TNS ? sh.ttm : 64;          // (the two-per-CU and 64 x 32 shapes exist as launches only)
+        if (cdiv(rem, shape) * (N / shape) > grid) shape = 64;               // more 32 x 32 tiles than workgroups (128 rows x 3072 columns at 336^2: 384): one 64 x 64 tile per
+        const int rem_tiles = cdiv(rem, shape) * (N / shape);                //   workgroup inside the launch still beats a launch of its own; the bits do not depend on the shape
+        if (rem_tiles <= grid) { g.rem_rows = rem; g.rem_tiles = rem_tiles; g.rem_shape = shape; merged = true; }
     }
     int rc = has_main ? launch_main(s, g, act, ncu, setok_prof_start_event(), p == 0 || merged ? setok_prof_stop_event() : nullptr) : SETOK_OK;
     if (timing && tim) {
