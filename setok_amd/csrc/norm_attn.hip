@@ -186,16 +186,26 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x,
     }
 }
 
-// rows of exactly 1024 bf16 (the ViT-L width): the row stays in registers between the passes (as layernorm_rows_kernel<bf16, 2>)
-__global__ __launch_bounds__(256) void row_stats_1024_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int rows, float eps) {
-    constexpr int V = 8, NCH = 2, C = 1024;
+// rows of exactly CT bf16 (1024: the ViT-L width; 768 / 1280: the pixel decoder's and ViT-H's): the row stays in registers between the passes (as
+// layernorm_rows_kernel<bf16, NCH, CT>); lanes past the end of the last 512-element chunk hold nothing.  (The 1024 instantiation keeps its round-2 name.)
+template <int CT>
+__device__ __forceinline__ void row_stats_rows(const bf16* __restrict__ x, float* __restrict__ stats, int rows, float eps) {
+    constexpr int V = 8, NCH = (CT + 511) / 512, C = CT;
+    static_assert(CT % 8 == 0, "whole 16-byte pieces");
     const int lane = threadIdx.x & 63;
+    const bool last_ok = ((NCH - 1) * 64 + lane) * V < C;                        // does this lane hold a piece of the last chunk?
     const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int row = wave0; row < rows; row += nwaves) {
         const bf16* xr = x + (int64_t)row * C;
         float buf[NCH][V];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) ld_vec<bf16>(xr + (k * 64 + lane) * V, buf[k]);
+        for (int k = 0; k < NCH; ++k) {
+            if (k + 1 < NCH || C % 512 == 0 || last_ok) ld_vec<bf16>(xr + (k * 64 + lane) * V, buf[k]);
+            else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) buf[k][i] = 0.f;
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
@@ -205,12 +215,17 @@ __global__ __launch_bounds__(256) void row_stats_1024_kernel(const bf16* __restr
         float q = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
+            if (k + 1 < NCH || C % 512 == 0 || last_ok) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) { const float d = buf[k][i] - mean; q += d * d; }
+                for (int i = 0; i < V; ++i) { const float d = buf[k][i] - mean; q += d * d; }
+            }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
         if (lane == 0) write_row_stats(stats, row, mean, rstd);
     }
 }
+__global__ __launch_bounds__(256) void row_stats_1024_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int rows, float eps) { row_stats_rows<1024>(x, stats, rows, eps); }
+template <int CT>
+__global__ __launch_bounds__(256) void row_stats_ct_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int rows, float eps) { row_stats_rows<CT>(x, stats, rows, eps); }
 
 extern "C" int setok_row_stats(void* stream, int dtype, const void* x, float* stats, int rows, int C, float eps) {
     SETOK_CHECK_ARG(x && stats, "setok_row_stats: null operand");
@@ -219,6 +234,8 @@ extern "C" int setok_row_stats(void* stream, int dtype, const void* x, float* st
     hipStream_t s = (hipStream_t)stream;
     const int grid = min(cdiv(rows, 4), 256 * 8);
     if (dtype == SETOK_BF16 && C == 1024) row_stats_1024_kernel<<<grid, 256, 0, s>>>((const bf16*)x, stats, rows, eps);
+    else if (dtype == SETOK_BF16 && C == 768) row_stats_ct_kernel<768><<<grid, 256, 0, s>>>((const bf16*)x, stats, rows, eps);
+    else if (dtype == SETOK_BF16 && C == 1280) row_stats_ct_kernel<1280><<<grid, 256, 0, s>>>((const bf16*)x, stats, rows, eps);
     else if (dtype == SETOK_BF16) row_stats_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)x, stats, rows, C, eps);
     else if (dtype == SETOK_F32) row_stats_kernel<float><<<grid, 256, 0, s>>>((const float*)x, stats, rows, C, eps);
     else return setok_fail(SETOK_EINVAL, "setok_row_stats: bad dtype %d", dtype);
