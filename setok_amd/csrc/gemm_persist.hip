@@ -507,6 +507,7 @@ __device__ __forceinline__ void gemm_tail_tile(const PArgs& g, const int tile, c
     constexpr int NI = TTM / 32, NJ = TTN / 32;             // 16 x 16 MFMA tiles per wave (wave = TTM / 2 rows x TTN / 2 columns)
     constexpr int LPT = NI + NJ;                            // LDS-DMA loads per lane per K-tile: TTM / 32 of A, TTN / 32 of W
     constexpr int STG = tail_stage(TTM, TTN);
+    static_assert(!LNK || TTM <= 64, "the folded LayerNorm's row values have 64 slots beside the bias row");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -560,7 +561,7 @@ __device__ __forceinline__ void gemm_tail_tile(const PArgs& g, const int tile, c
     // A second version that also read the NEXT pair's fragments under the current pair's MFMAs (two register sets, the pair's stages refilled one
     // barrier earlier) was slower than this one (fc2 15.8 us, one image 1.75 ms) and is not kept.  The MFMA order — K-tile kt, then kt + 1, each
     // k-step 0 then 1 — is unchanged: bits identical to every other bf16 GEMM kernel.
-    constexpr bool PAIR = NS >= 8;
+    constexpr bool PAIR = NS >= 6;                          // (six stages: the 128 x 64 shape, 24 KiB per stage — two K-tiles in flight beyond the pair)
     for (int kt = 0; kt < (PAIR ? NS - 2 : NS - 1) && kt < nk; ++kt) issue(kt);
 
     f32x4 acc[NI][NJ];                                      // this wave's (TTM / 2) x (TTN / 2): NI x NJ MFMA tiles of 16 x 16
@@ -705,15 +706,37 @@ template <int ACT, bool LNK = false, int TTM = 64, int TTN = 64, int NS = TNS>
 __global__ __launch_bounds__(256) void gemm_tail_kernel(PArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_tail_tile<ACT, LNK, TTM, TTN, NS>(g, blockIdx.x, smem);
+    if constexpr (TTM == 128) {
+        // the 128 x 64 shape is launched for whole 128-row tiles that fill the chip in ONE round (eight images' fc2: 2048 x 1024 -> 256 tiles); the few rows behind
+        // them (8 of 2056) are finished here as 32 x 32 tiles by workgroups 0 .. rem_tiles - 1, like the ping-pong kernel's remainder
+        if (g.rem_rows > 0 && (int)blockIdx.x < g.rem_tiles) {
+            s_barrier_lgkm();                               // everyone is out of the big tile's staging rows
+            PArgs t = g;
+            t.A = g.A + (int64_t)g.M * g.lda;
+            t.C = g.C + (int64_t)g.M * g.ldc;
+            if (g.res) t.res = g.res + (int64_t)g.M * g.ldc;
+            t.M = g.rem_rows; t.tilesM = (g.rem_rows + 31) / 32; t.tilesN = g.N / 32; t.m_dev = nullptr; t.rem_rows = 0;
+            gemm_tail_tile<ACT, LNK, 32, 32, TNS>(t, blockIdx.x, smem);
+        }
+    }
 }
 
 // Shape of the small-tile launch for a problem of M x N outputs (host side): how many workgroups the default 64 x 64 tiles give against the CUs.
 // SETOK_GEMM_SMALL_SHAPE=0 keeps the default everywhere (A/B runs).
 struct TailShape { int ttm, ttn, ns; };
-static TailShape tail_shape_for(int M, int N, int ncu) {
+// (`whole`: the caller launches the WHOLE problem with this shape — not a remainder — has no folded LayerNorm and no device-side row count: the 128 x 64 shape may be picked)
+static TailShape tail_shape_for(int M, int N, int ncu, bool whole = false) {
     static const bool off = [] { const char* e = getenv("SETOK_GEMM_SMALL_SHAPE"); return e && e[0] == '0'; }();
     if (off) return {64, 64, TNS};
     const int t64 = cdiv(M, TT) * cdiv(N, 64);
+    // Round 5: more 64 x 64 tiles than CUs, but the whole 128-row tiles of 64 columns fit ONE round and the rows behind them are few: 128 x 64 tiles (twice the MFMAs
+    // per K-tile under the same latency chain) + the remainder inside the launch.  Eight images: fc2 59 -> 47 us, proj 19 -> 10 us, the step 5.0 -> 4.58 ms; with HALF
+    // a round of such tiles (four images: 128) the two-per-CU 64 x 64 launch stays ahead (3.65 against 4.17 ms).  SETOK_GEMM_SHAPE_128=0: off (A/B).
+    static const bool s128 = [] { const char* e = getenv("SETOK_GEMM_SHAPE_128"); return !(e && e[0] == '0'); }();
+    if (s128 && whole && N % 64 == 0 && t64 > ncu) {
+        const int main_tiles = (M / 128) * (N / 64), rem = M % 128;
+        if (main_tiles > ncu / 2 && main_tiles <= ncu && (rem == 0 || cdiv(rem, 32) * (N / 32) <= main_tiles)) return {128, 64, 6};
+    }
     if (t64 * 4 <= ncu && N % 32 == 0) return {32, 32, TNS};          // a quarter of the chip: four times the workgroups
 #ifndef SETOK_NO_TWO_PER_CU_3232
     if (N % 32 == 0 && cdiv(M, 32) * cdiv(N, 32) <= 2 * ncu) return {32, 32, TNS};   // round 4: up to TWO 32 x 32 workgroups per CU (66.5 KiB of LDS each) in one round
@@ -725,22 +748,29 @@ static TailShape tail_shape_for(int M, int N, int ncu) {
 
 template <int TTM, int TTN, int NS>
 static int launch_tail_shape(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1) {
+    constexpr bool LN_OK = TTM <= 64;                       // (the 128 x 64 shape has no folded-LayerNorm form)
     static SetokDeviceOnce once;
     if (!once.run([] {
             bool ok = true;
             const void* fns[] = {(const void*)gemm_tail_kernel<0, false, TTM, TTN, NS>, (const void*)gemm_tail_kernel<1, false, TTM, TTN, NS>,
-                                 (const void*)gemm_tail_kernel<2, false, TTM, TTN, NS>, (const void*)gemm_tail_kernel<0, true, TTM, TTN, NS>,
-                                 (const void*)gemm_tail_kernel<1, true, TTM, TTN, NS>, (const void*)gemm_tail_kernel<2, true, TTM, TTN, NS>};
+                                 (const void*)gemm_tail_kernel<2, false, TTM, TTN, NS>};
             for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(TTM, TTN, NS)) == hipSuccess;
+            if constexpr (LN_OK) {
+                const void* lfns[] = {(const void*)gemm_tail_kernel<0, true, TTM, TTN, NS>, (const void*)gemm_tail_kernel<1, true, TTM, TTN, NS>,
+                                      (const void*)gemm_tail_kernel<2, true, TTM, TTN, NS>};
+                for (const void* f : lfns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(TTM, TTN, NS)) == hipSuccess;
+            }
             return ok; }))
         return setok_fail(SETOK_ELAUNCH, "setok_linear: cannot raise the dynamic LDS limit");
     constexpr int LDS = tail_lds(TTM, TTN, NS);
     const int grid = g.tilesM * g.tilesN;
     const dim3 gr(grid), bl(256);
     if (g.ln_stats) {
-        if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-        else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
-        else setok_launch(gemm_tail_kernel<2, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        if constexpr (LN_OK) {
+            if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+            else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+            else setok_launch(gemm_tail_kernel<2, true, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
+        } else return setok_fail(SETOK_EINVAL, "setok_linear_ln: no %d x %d small-tile kernel with a folded LayerNorm", TTM, TTN);
     } else if (act == SETOK_ACT_NONE) setok_launch(gemm_tail_kernel<0, false, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
     else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_tail_kernel<1, false, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
     else setok_launch(gemm_tail_kernel<2, false, TTM, TTN, NS>, gr, bl, LDS, s, e0, e1, g);
@@ -750,6 +780,7 @@ static int launch_tail_shape(hipStream_t s, const PArgs& g, int act, hipEvent_t 
 
 // g.tilesM / g.tilesN must have been computed for `sh` (cdiv(M, sh.ttm), cdiv(N, sh.ttn)).
 int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_t e1, TailShape sh) {
+    if (sh.ttm == 128) return launch_tail_shape<128, 64, 6>(s, g, act, e0, e1);
     if (sh.ttm == 32) return launch_tail_shape<32, 32, TNS>(s, g, act, e0, e1);
     if (sh.ttn == 32) return launch_tail_shape<64, 32, TNS>(s, g, act, e0, e1);
     if (sh.ns == 4) return launch_tail_shape<64, 64, 4>(s, g, act, e0, e1);
@@ -1523,8 +1554,12 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 // 64 x 64 kernel over the whole problem.
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                           bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev) {
-    const TailShape sh = tail_shape_for(M, N, cu_count());
+    const TailShape sh = tail_shape_for(M, N, cu_count(), !ln_stats && !m_dev);
     PArgs t{A, W, bias, res, C, lda, ldc, M, N, K, cdiv(M, sh.ttm), cdiv(N, sh.ttn), 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, ln_stats, ln_colsum, m_dev};
+    if (sh.ttm == 128) {                                    // whole 128-row tiles as the grid, the rows behind them inside the launch (gemm_tail_kernel)
+        t.M = M / 128 * 128; t.tilesM = M / 128;
+        t.rem_rows = M % 128; t.rem_tiles = cdiv(M % 128, 32) * (N / 32); t.rem_shape = 32;
+    }
     const hipEvent_t e0 = setok_prof_start_event();
     return launch_tail(s, t, act, e0, setok_prof_stop_event(), sh);
 }

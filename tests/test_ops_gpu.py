@@ -108,7 +108,7 @@ def test_linear_bf16_rows_do_not_depend_on_the_kernel(act, use_res, N, K):
     b = _rand(N, seed=13).to(DEV)
     r = _rand(M, N, seed=14).bfloat16().to(DEV) if use_res else None
     big = ops.linear(a, w, b, r, act=act)
-    for m in (1, 63, 257, 1028, 4112):
+    for m in (1, 63, 257, 1028, 2056, 2048, 4112):          # 2056 / 2048 at N = 1024: 128 x 64 tiles in one round + 8 / 0 rows behind them inside the launch (round 5)
         small = ops.linear(a[:m].contiguous(), w, b, None if r is None else r[:m].contiguous(), act=act)
         assert torch.equal(small, big[:m]), m
 
