@@ -191,7 +191,7 @@ int setok_vit_assemble(void* stream, int dtype, const void* patch_embed, const v
  * setok_layernorm. */
 
 /* stats row r (8 floats): [0], [1] the compact activation-side MFMA fragment of (-mean_r, 1 / rstd_r) (two bf16 pairs: two-way splits),
- * [4] rstd_r = 1 / sqrt(var + eps), [5] mean_r, the rest 0.  Two-pass fp32 statistics in setok_layernorm's order; rows x C, `dtype`. */
+ * [2] and [4] rstd_r = 1 / sqrt(var + eps), [5] mean_r, the rest 0.  Two-pass fp32 statistics in setok_layernorm's order; rows x C, `dtype`. */
 int setok_row_stats(void* stream, int dtype, const void* x, float* stats, int rows, int C, float eps);
 
 /* Once per weight load: W (N, K) bf16, gamma / beta (K) fp32, bias (N) fp32 or NULL ->

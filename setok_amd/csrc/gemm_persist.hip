@@ -845,6 +845,9 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #ifndef PP_RESYNC
 #define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
 #endif
+#ifndef PP_LN_PACK
+#define PP_LN_PACK 1        // 1: the folded LayerNorm's start values are 6 loads per wave — the column fragments in EVERY lane group, row block t's fragment + rstd as ONE
+#endif                      // 16-byte load in lane group t / 2, the start MFMA of block t masking the other groups; 0: 14 loads, fragments in lanes 0-15 (rounds 3-4)
 #ifndef PP_MERGE_REM
 #define PP_MERGE_REM 1      // 1: a launch finishes its remainder rows itself (see the end of gemm_pp_body); 0: they are a launch of the small-tile kernel (rounds 3-4)
 #endif
@@ -858,7 +861,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     constexpr int NSTORE = 16;
     // entries of the vector-memory queue a tile's epilogue puts BEHIND the A quarters of the next tile's K-tile 1: the next tile's start values
     // (bias / LN fragments: 4 / 5 ordinary loads) and, with a residual, the residual rows of passes 1-3 (12 loads); + the 16 stores
-    constexpr int NAUX = (LNK ? 14 : 4) + (RESK ? 12 : 0);
+    constexpr int NAUX = (LNK ? (PP_LN_PACK ? 6 : 14) : 4) + (RESK ? 12 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3;                                // wave row == GRP
@@ -983,6 +986,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     float nrs[2], ers[2];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x4 ncd[4]; f32x2 nrd[8];                             // the operand fragments of the start MFMAs as the lanes hold them (k-slots 0-7 live in lanes 0-15)
+    f32x4 npk[2];                                           // PP_LN_PACK: words 0-2 of the statistics records of row blocks 2 g4, 2 g4 + 1 (fragment, fragment, rstd)
     // The loads are inline assembly and the wait for them is explicit (start_ready): as ordinary loads the compiler waited for them at the loop
     // header with the counts of the kernel-entry path (`vmcnt(0)` for the last one) — on the loop's back edge that is a full drain of the
     // previous tile's sixteen stores, ~2.5 k ticks per tile.  
@@ -993,6 +997,16 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
         if constexpr (LNK) {
             // Every lane fetches its own operand registers: lanes 0-15 the fragments, the others zeros (one 256-byte line of zeros for all of
             // them) — 12 loads instead of 3, and the tile start has no cross-lane traffic (40 ds_bpermute + 48 selects per wave before).
+#if PP_LN_PACK
+            // Round 5 (second half): 6 loads instead of 14 in an epilogue whose length is its vector-memory instruction count.  The start MFMA contracts over 32
+            // k-slots of which 8 carry the rank-2 correction: the COLUMN fragment sits in all four lane groups (the same address for the four lanes of a column),
+            // the ROW fragment of block t only in group t / 2 (the MFMA of block t zeroes the other groups' operand) — the same eight products, and one 16-byte
+            // load per row brings fragment and rstd (setok_row_stats writes rstd as word 2 of the record as well).
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ld16(ncd[j], g.ln_colsum + 4 * (int64_t)(n0_ + wn * 64 + j * 16 + l15));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ld16(npk[i], g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15));
+#else
             const bool own = g4 == 0;
             const float* zr = g.zero_bias;
 #pragma unroll
@@ -1001,6 +1015,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             for (int t = 0; t < 8; ++t) ld8(nrd[t], own ? g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + t * 16 + l15) : zr + 2 * l15);
 #pragma unroll
             for (int i = 0; i < 2; ++i) ld4(nrs[i], g.ln_stats + 8 * (int64_t)(m0_ + GRP * 128 + (2 * g4 + i) * 16 + l15) + 4);
+#endif
         } else {
             const float* bp = (g.bias ? g.bias + n0_ : g.zero_bias) + (g.bias ? wn * 64 : 0) + 4 * g4;
 #pragma unroll
@@ -1013,8 +1028,12 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     constexpr int NBEHIND = NSTORE + (RESK ? 8 : 0);
     auto start_ready = [&]() {
         if constexpr (LNK)
+#if PP_LN_PACK
+            asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(ncd[0]), "+v"(ncd[1]), "+v"(ncd[2]), "+v"(ncd[3]), "+v"(npk[0]), "+v"(npk[1]) : [n] "n"(NBEHIND) : "memory");
+#else
             asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(ncd[0]), "+v"(ncd[1]), "+v"(ncd[2]), "+v"(ncd[3]), "+v"(nrd[0]), "+v"(nrd[1]), "+v"(nrd[2]), "+v"(nrd[3]),
                          "+v"(nrd[4]), "+v"(nrd[5]), "+v"(nrd[6]), "+v"(nrd[7]), "+v"(nrs[0]), "+v"(nrs[1]) : [n] "n"(NBEHIND) : "memory");
+#endif
         else
             asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(nbv[0]), "+v"(nbv[1]), "+v"(nbv[2]), "+v"(nbv[3]) : [n] "n"(NBEHIND) : "memory");
     };
@@ -1053,14 +1072,24 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #else
         if constexpr (LNK) {
 #endif
+#if PP_LN_PACK
+            ers[0] = npk[0][2]; ers[1] = npk[1][2];
+#else
             ers[0] = nrs[0]; ers[1] = nrs[1];
+#endif
             asm volatile("" : "+v"(ers[0]), "+v"(ers[1]));   // values of THIS point: without it the epilogue's first use waits `vmcnt(0)` — for the operand DMA in flight
             f32x4 z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
+#if PP_LN_PACK
+                const bool mine = g4 == (t >> 1);                                        // this lane group carries row block t's fragment
+                const float f0 = mine ? npk[t & 1][0] : 0.f, f1 = mine ? npk[t & 1][1] : 0.f;
+                const f32x4 v = {f0, f0, f1, f1};
+#else
                 const f32x4 v = {nrd[t][0], nrd[t][0], nrd[t][1], nrd[t][1]};            // (-mean hi, lo) twice, (1 / rstd hi, lo) twice
+#endif
                 const bf16x8 rfr = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ncd[j]), rfr, z, 0, 0, 0);

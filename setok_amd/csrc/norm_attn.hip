@@ -150,11 +150,11 @@ extern "C" int setok_layernorm(void* stream, int dtype, const void* x, const flo
 //   the weight fold, once per weight load:  W' = bf16(gamma * W),  c = W' 1 (fp32, ascending k),  b' = b + W beta.
 // --------------------------------------------------------------------------------------------
 // stats row = 8 floats: [0] = (-mean hi, lo) and [1] = (1 / rstd hi, lo) as bf16 pairs — the compact form of the activation-side fragment
-// [mh, ml, mh, ml, sh, sl, sh, sl] (the GEMM duplicates the two words) — [2], [3] = 0, [4] = rstd, [5] = mean, [6], [7] = 0
+// [mh, ml, mh, ml, sh, sl, sh, sl] (the GEMM duplicates the two words) — [2] = rstd (again), [3] = 0, [4] = rstd, [5] = mean, [6], [7] = 0
 __device__ inline void write_row_stats(float* stats, int64_t row, float mean, float rstd) {
     const f32x4 fr = __builtin_bit_cast(f32x4, ln_row_frag(mean, rstd));
     f32x4* o = reinterpret_cast<f32x4*>(stats + 8 * row);
-    const f32x4 head = {fr[0], fr[2], 0.f, 0.f};
+    const f32x4 head = {fr[0], fr[2], rstd, 0.f};             // (rstd once more as word 2: the ping-pong GEMM fetches fragment + rstd as ONE 16-byte load)
     o[0] = head;
     const f32x4 tail = {rstd, mean, 0.f, 0.f};
     o[1] = tail;
