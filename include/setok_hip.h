@@ -49,6 +49,9 @@ int setok_device_info(char* name_host, int name_cap, int* cu_count_host);
  * bytes = algorithmic bytes of the call; ms = event duration.  Call start / stop while no other library call is in flight. */
 int setok_profile_start(void);
 int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* ms, int cap);
+/* Between start and stop: pause != 0 stops attaching events to launches (the records so far stay), 0 resumes.  An event pair per launch costs ~4 us of device
+ * time: a caller timing many steps probes some of them. */
+int setok_profile_pause(int pause);
 
 /* ---- the whole path behind one call (host-language-neutral entry) -------------------------------------------------
  * `SetokTokenizer.forward` (src/model/setok/tokenizer.py:157-182): tower (clip_encoder.py:50-62, HF CLIP ViT hidden_states[select_layer],

@@ -28,6 +28,7 @@ RESTYPES = {"setok_last_error": C.c_char_p, "setok_ctx_error": C.c_char_p, "seto
 SIGNATURES = {
     "setok_profile_start": [],
     "setok_profile_stop": [_vp, _vp, _vp, _vp, _vp, _i],
+    "setok_profile_pause": [_i],
     "setok_create": [C.POINTER(SetokConfig), C.POINTER(_vp)],
     "setok_destroy": [_vp],
     "setok_ctx_error": [_vp],

@@ -44,6 +44,7 @@ struct ProfRec { int kind, cls; double work, bytes; hipEvent_t e0, e1; bool atta
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 volatile int g_prof_on = 0;
+bool g_prof_open = false;                       // between setok_profile_start and setok_profile_stop (g_prof_on drops while paused)
 thread_local std::vector<int> g_open;               // indices of this thread's open attach-scopes, innermost last
 }  // namespace
 
@@ -145,6 +146,17 @@ extern "C" int setok_profile_start(void) {
     g_prof_ring_used = 0;
     g_rows_last_dev = nullptr; g_rows_last_host = nullptr; g_rows_last_index = -2;
     g_prof_on = 1;
+    g_prof_open = true;
+    return SETOK_OK;
+}
+
+// Between setok_profile_start and setok_profile_stop: pause != 0 stops attaching events to launches (what was recorded stays), 0 resumes — a caller that times
+// many steps probes a few of them (an event pair per GEMM launch is not free: ~4 us of device time per launch, 0.43 ms of a 42 ms step) without losing the rest.
+extern "C" int setok_profile_pause(int pause) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_open) return setok_fail(SETOK_EINVAL, "setok_profile_pause: no recording is open (setok_profile_start)");
+    g_prof_on = pause ? 0 : 1;
+    g_rows_last_dev = nullptr;                       // (records are no longer consecutive across a pause)
     return SETOK_OK;
 }
 
@@ -152,6 +164,7 @@ extern "C" int setok_profile_start(void) {
 extern "C" int setok_profile_stop(int* kind, int* cls, double* work, double* bytes, float* ms, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = 0;
+    g_prof_open = false;
     int n = 0, dropped = 0;
     for (auto& r : g_prof) {
         float t = 0.f;

@@ -64,6 +64,11 @@ def profile_start() -> None:
     _lib.call("setok_profile_start")
 
 
+def profile_pause(pause: bool = True) -> None:
+    """Between profile_start() and profile_stop(): stop (True) / resume (False) attaching events to launches; what was recorded stays."""
+    _lib.call("setok_profile_pause", 1 if pause else 0)
+
+
 def profile_stop():
     """Synchronise and return [{kernel, flops, ms, bytes}] for every launch the library recorded since profile_start()."""
     import numpy as np
