@@ -481,6 +481,7 @@ def main():
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "probe_every": pe,                              # measurement mode of value / ms_per_step: 1 = rounds 1-4's (every step probed), 4 = default since round 5
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_desc, "batch_per_gpu": B, "global_batch": world * B,

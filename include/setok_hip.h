@@ -15,7 +15,14 @@
  *     nothing, and synchronises nothing — outputs and workspaces are caller-allocated (the context
  *     entry points are the documented exception: they own the weights; setok_encode synchronises only on request);
  *   - `dtype` selects the activation/weight element type: SETOK_F32 (parity mode; fp32 MFMA,
- *     exact fma chains) or SETOK_BF16 (throughput mode; bf16 MFMA, fp32 accumulation);
+ *     exact fma chains), SETOK_BF16 (throughput mode; bf16 MFMA, fp32 accumulation) or — since ABI 9 —
+ *     SETOK_F16 (IEEE half, fp16 MFMA at the bf16 rate, fp32 accumulation: what the reference's inference
+ *     loader and its non-`--bf16` training launches cast the tower to, src/model/builder.py:43,135-136,
+ *     src/train/train_setokim.py:326,348,374).  The 16-bit kernels are written ONCE against "a 16-bit float
+ *     element with fp32 accumulation" and compiled twice: libsetok_hip.so serves SETOK_F32 + SETOK_BF16,
+ *     libsetok_hip_f16.so (the same sources under -DSETOK_HALF, the same exported names) serves SETOK_F32 +
+ *     SETOK_F16; each refuses the other's 16-bit code, a host binds the one(s) it needs (dlopen with
+ *     RTLD_LOCAL: both export this header's names; the Python host routes by tensor dtype, setok_amd/_lib.py);
  *     biases, LayerNorm affine parameters, scores and distances are always fp32;
  *   - matrices are row-major and dense unless a leading dimension is given;
  *   - return value: 0 on success, a negative SETOK_E* code otherwise; setok_last_error() returns
@@ -30,9 +37,9 @@
 extern "C" {
 #endif
 
-#define SETOK_ABI_VERSION 8
+#define SETOK_ABI_VERSION 9
 
-enum { SETOK_F32 = 0, SETOK_BF16 = 1 };
+enum { SETOK_F32 = 0, SETOK_BF16 = 1, SETOK_F16 = 2 };
 enum { SETOK_ACT_NONE = 0, SETOK_ACT_QUICK_GELU = 1, SETOK_ACT_GELU_ERF = 2 };
 enum { SETOK_OK = 0, SETOK_EINVAL = -1, SETOK_ELAUNCH = -2, SETOK_EUNSUPPORTED = -3 };
 
@@ -72,8 +79,8 @@ typedef struct setok_config {
     /* head: ctor kwargs of SetokTokenizer (tokenizer.py:14-34); hidden_dim == tower hidden_size */
     int token_feat_dim, nheads, dim_feedforward, inner_cluster_layers, intra_cluster_layers, min_cluster_num;
     float threshold;
-    int dtype;                   /* SETOK_BF16 (throughput mode) or SETOK_F32 (parity mode) */
-    int fold_layernorm;          /* bf16 only: fold layer_norm1 / layer_norm2 of the tower into the q|k|v / fc1 GEMMs */
+    int dtype;                   /* SETOK_BF16 / SETOK_F16 (throughput mode; F16 in libsetok_hip_f16.so) or SETOK_F32 (parity mode) */
+    int fold_layernorm;          /* 16-bit modes only: fold layer_norm1 / layer_norm2 of the tower into the q|k|v / fc1 GEMMs */
 } setok_config;
 
 int setok_create(const setok_config* cfg, setok_ctx** out);
@@ -91,7 +98,12 @@ int setok_load_weight(setok_ctx* ctx, void* stream, const char* name, const void
  * one) and builds the fused q|k|v matrices, the padded patch matrix and the folded LayerNorm operands. */
 int setok_weights_ready(setok_ctx* ctx, void* stream);
 
-/* Bytes of 256-byte-aligned device workspace setok_encode needs for a batch of B images. */
+/* Bytes of 256-byte-aligned device workspace setok_encode needs for a batch of B images.
+ * STREAM-ORDER CONTRACT of the workspace (and of every output buffer of setok_encode): the call's launches read and write it on `stream`, and
+ * since ABI 8 the counts_host form RETURNS WHILE THE LAST OF THEM ARE STILL RUNNING.  The buffers therefore belong to `stream` until work enqueued
+ * behind the call on that stream has run: reuse on the same stream needs nothing; reuse, reading (hipMemcpyAsync on another or a non-blocking
+ * stream) or freeing from ANY OTHER stream or from the host needs an event recorded on `stream` after the call (or hipStreamSynchronize(stream)).
+ * hipFree / hipFreeAsync on another stream without that order is a use-after-free, exactly as for any other asynchronous launch. */
 int64_t setok_encode_workspace_bytes(const setok_ctx* ctx, int B);
 
 /* images (B, 3, image_size, image_size) in the compute dtype -> tokens: packed (sum_b L_b, token_feat_dim) rows, image b owning rows

@@ -1,7 +1,12 @@
-"""ctypes binding of libsetok_hip.so (C ABI: include/setok_hip.h).
+"""ctypes binding of libsetok_hip.so and libsetok_hip_f16.so (C ABI: include/setok_hip.h).
 
 There is NO fallback: if the library is missing or a call fails this raises — the product path never
-routes through the CPU oracle or plain torch ops."""
+routes through the CPU oracle or plain torch ops.
+
+Two builds of the same sources export the same ABI (include/setok_hip.h, `dtype`): libsetok_hip.so serves float32 + bfloat16,
+libsetok_hip_f16.so float32 + float16 (the reference's inference loader casts the tower to torch.float16: src/model/builder.py:43,135-136).
+`call` routes by the dtype code among the arguments — ops._code(torch.float16) returns the marked integer F16 — or by `half=True` for the
+entry points whose element type is implied (setok_linear_ln, setok_ln_fold, the context calls)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -9,8 +14,16 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SETOK_HIP_LIB") or os.path.join(_HERE, "libsetok_hip.so")   # SETOK_HIP_LIB: another build of the same ABI (A/B runs)
+LIB_PATH_F16 = os.environ.get("SETOK_HIP_LIB_F16") or os.path.join(_HERE, "libsetok_hip_f16.so")
+
+
+class _HalfCode(int):
+    """SETOK_F16 as an int that also says WHICH library serves it: `call` sends every call carrying one to libsetok_hip_f16.so."""
+    __slots__ = ()
+
 
 F32, BF16 = 0, 1
+F16 = _HalfCode(2)
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 
@@ -81,33 +94,38 @@ SIGNATURES = {
     "setok_splice_rows_bwd": [_vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i],
 }
 
-_lib = None
+_libs = {}
 
 
 class SetokHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load the HIP library once; raise loudly if it is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
+def load(half: bool = False):
+    """Load the HIP library (half=True: its fp16 build) once; raise loudly if it is not built."""
+    lib = _libs.get(bool(half))
+    if lib is not None:
+        return lib
+    path = LIB_PATH_F16 if half else LIB_PATH
+    if not os.path.isfile(path):
         raise SetokHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C setok_amd/csrc`. There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)                    # RTLD_LOCAL: the two builds export the same names and must not see each other's
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, _i)
-    _lib = lib
+    _libs[bool(half)] = lib
     return lib
 
 
-def call(name: str, *args) -> None:
-    lib = load()
+def is_half(*args) -> bool:
+    return any(type(a) is _HalfCode for a in args)
+
+
+def call(name: str, *args, half: bool = False) -> None:
+    lib = load(half or is_half(*args))
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise SetokHipError(f"{name} failed (code {rc}): {lib.setok_last_error().decode()}")

@@ -181,7 +181,7 @@ class CLIPVisionTower(PackCacheMixin, nn.Module):
         wp[:, :3 * p * p] = vt.embeddings.patch_embedding.weight.detach().reshape(C, -1)
         # bf16 throughput mode: layer_norm1 / layer_norm2 are folded into the q|k|v and fc1 GEMMs (ops.linear_ln); SETOK_LN_FOLD=0 keeps the
         # separate LayerNorm pass (A/B runs).  The fp32 parity mode always keeps it.
-        fold = dt == torch.bfloat16 and vt.device.type == "cuda" and os.environ.get("SETOK_LN_FOLD", "1") != "0" and C % 64 == 0 \
+        fold = dt in ops.LOW and vt.device.type == "cuda" and os.environ.get("SETOK_LN_FOLD", "1") != "0" and C % 64 == 0 \
             and cfg.intermediate_size % 64 == 0
         layers = []
         for l in vt.encoder.layers:

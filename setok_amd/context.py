@@ -37,8 +37,9 @@ class EncodeContext:
             token_feat_dim=tok.token_feat_dim, nheads=blk.num_heads, dim_feedforward=blk.mlp.fc1.out_features,
             inner_cluster_layers=len(tok.inner_encoder.layers), intra_cluster_layers=len(tok.inter_encoder.layers),
             min_cluster_num=tok.min_cluster_num, threshold=float(tok.threshold), dtype=_code(dt), fold_layernorm=1 if fold_layernorm else 0)
+        self._half = dt == torch.float16                              # which build of the library owns this context (libsetok_hip_f16.so for float16)
         self.handle = C.c_void_p()
-        _lib.call("setok_create", C.byref(sc), C.byref(self.handle))
+        _lib.call("setok_create", C.byref(sc), C.byref(self.handle), half=self._half)
         self.device, self.dtype = dev, dt
         self.N = (cfg.image_size // cfg.patch_size) ** 2
         self.image_size = cfg.image_size
@@ -53,12 +54,12 @@ class EncodeContext:
                 if _skip(name):
                     continue
                 t = t.detach()
-                if t.dtype not in (torch.float32, torch.bfloat16):
+                if t.dtype not in (torch.float32, dt):
                     t = t.float()
                 t = t.to(dev).contiguous()
                 shape = (C.c_int64 * t.dim())(*t.shape)
-                _lib.call("setok_load_weight", self.handle, st, name.encode(), t.data_ptr(), _code(t.dtype), shape, t.dim())
-            _lib.call("setok_weights_ready", self.handle, st)
+                _lib.call("setok_load_weight", self.handle, st, name.encode(), t.data_ptr(), _code(t.dtype), shape, t.dim(), half=self._half)
+            _lib.call("setok_weights_ready", self.handle, st, half=self._half)
         torch.cuda.current_stream().synchronize()                     # the staging copies above read tensors that may die now
 
     def __deepcopy__(self, memo):
@@ -67,7 +68,7 @@ class EncodeContext:
     def __del__(self):
         try:
             if getattr(self, "handle", None):
-                _lib.load().setok_destroy(self.handle)
+                _lib.load(self._half).setok_destroy(self.handle)
                 self.handle = None
         except Exception:
             pass
@@ -81,18 +82,34 @@ class EncodeContext:
         ONCE, after everything is queued, because a RaggedTokens needs host-side shapes — and waits for THEM only (they are final behind the
         clustering): the returned tensors are complete in stream order, like the result of any torch operation, while the head's last launches may
         still be running when the call returns (so the caller's next launches queue up behind them instead of finding the device idle).  sync=False skips even that: the call only enqueues
-        work (it can be captured into a graph) and returns (tokens at the worst-case capacity (B * N, D), counts as a DEVICE int32 tensor, idx,
+        work (it can be captured into a graph — after one eager call of the same batch size, or on a caller-owned `ws`; the captured launches then
+        point into that workspace, and eager calls of that batch size on other streams are the caller's to order against the replays) and returns (tokens at the worst-case capacity (B * N, D), counts as a DEVICE int32 tensor, idx,
         score, index_down); rows of `tokens` past sum(counts) are unspecified."""
         B, N, dev = images.shape[0], self.N, self.device
         x = images.to(device=dev, dtype=self.dtype).contiguous()
-        nbytes = _lib.load().setok_encode_workspace_bytes(self.handle, B)
+        nbytes = _lib.load(self._half).setok_encode_workspace_bytes(self.handle, B)
         if ws is not None:                                                # a caller-owned workspace (GraphedEncode: the captured launches point into it)
             if ws.numel() < nbytes or ws.dtype != torch.uint8 or ws.device != dev:
                 raise ValueError(f"workspace must be a uint8 tensor of >= {nbytes} bytes on {dev}")
         else:
             ws = self._ws.get(B)
+        cur = torch.cuda.current_stream(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and sync:
+            raise ValueError("encode(sync=True) reads the token counts on the host, which a stream capture cannot contain: capture encode(sync=False)")
         if ws is None or ws.numel() < nbytes:
-            self._ws = {B: torch.empty(nbytes, dtype=torch.uint8, device=dev)}            # one batch size cached: the workspace is the activations' size
+            if capturing:
+                raise _lib.SetokHipError(f"encode(sync=False) under stream capture needs a workspace that exists already: call it once eagerly with "
+                                         f"batch size {B} first, or pass ws= (GraphedEncode does)")
+            # one batch size cached: the workspace is the activations' size.  The workspace it replaces may still be in use by a call that returned
+            # early (ABI 8) on ANOTHER stream: order this stream behind that call and tell the allocator, so the block is not handed out again before
+            # the launches reading it are done (ADVICE r05)
+            ev = self.__dict__.get("_ws_free")
+            if ev is not None:
+                cur.wait_event(ev)
+            for old in self._ws.values():
+                old.record_stream(cur)
+            self._ws = {B: torch.empty(nbytes, dtype=torch.uint8, device=dev)}
             ws = self._ws[B]
         tokens = torch.empty((B * N, self.D), dtype=self.dtype, device=dev)
         counts = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -105,12 +122,15 @@ class EncodeContext:
         if token_mask is not None:
             token_mask = token_mask.to(device=dev, dtype=torch.float32).contiguous()
             assert token_mask.numel() == B * N
-        if ws is self._ws.get(B):
+        own_ws = ws is self._ws.get(B) and not capturing
+        if own_ws:
             # the context's own workspace is shared by every call of this batch size: since ABI 8 a call returns while its last launches are
-            # still running, so a call made on ANOTHER stream waits for the previous call's end first (a no-op on the same stream)
+            # still running, so a call made on ANOTHER stream waits for the previous call's end first (a no-op on the same stream).  NOT under
+            # stream capture: a capturing stream must not wait on an event recorded outside the capture, and an event recorded inside
+            # one is no event an eager call may wait on — a captured call is ordered by the graph launch, on the capturing stream, like its replays.
             ev = self.__dict__.get("_ws_free")
             if ev is not None:
-                torch.cuda.current_stream(dev).wait_event(ev)
+                cur.wait_event(ev)
         counts_h = (C.c_int32 * B)() if sync else None
         total = C.c_int64(0)
         sx, sg, si = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -118,12 +138,12 @@ class EncodeContext:
                   None if noise is None else noise.data_ptr(), None if token_mask is None else token_mask.data_ptr(),
                   ws.data_ptr(), ws.numel(), tokens.data_ptr(), counts.data_ptr(), idx.data_ptr(), score.data_ptr(), index_down.data_ptr(),
                   counts_h, C.byref(total) if sync else None, C.byref(sx) if return_stages else None, C.byref(sg) if return_stages else None,
-                  C.byref(si) if return_stages else None)
-        if ws is self._ws.get(B):
+                  C.byref(si) if return_stages else None, half=self._half)
+        if own_ws:
             ev = self.__dict__.get("_ws_free")
             if ev is None:
                 ev = self.__dict__["_ws_free"] = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
+            ev.record(cur)
         if not sync:
             if return_stages:
                 raise ValueError("return_stages needs the host-side counts (sync=True)")
@@ -159,7 +179,7 @@ class GraphedEncode:
     def _capture(self, ctx: "EncodeContext"):
         self.ctx, B = ctx, self.B
         self.images = torch.zeros((B, 3, ctx.image_size, ctx.image_size), dtype=ctx.dtype, device=ctx.device)
-        nbytes = _lib.load().setok_encode_workspace_bytes(ctx.handle, B)
+        nbytes = _lib.load(ctx._half).setok_encode_workspace_bytes(ctx.handle, B)
         self._ws = torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)          # the graph's OWN workspace: eager encode() calls of the same batch size
         ctx.encode(self.images, self.k, self.threshold, sync=False, ws=self._ws)       # (any stream) never touch it.  Warm-up: one-time attribute calls stay out of the capture
         torch.cuda.synchronize(ctx.device)

@@ -7,10 +7,28 @@
 
 #include "../../include/setok_hip.h"
 
+// The 16-bit element type.  Every 16-bit kernel of the library is written against "a 16-bit float element, fp32 accumulation" under the name
+// `bf16` — the type of the BASELINE metric — and nothing in them depends on the exponent width except the three places marked SETOK_HALF
+// (the two-way / three-way exact splits that feed fp32 values to the matrix pipe).  The library is compiled TWICE from these sources:
+//   libsetok_hip.so       bf16 = __bf16,    v_mfma_f32_*_bf16, serves SETOK_F32 + SETOK_BF16
+//   libsetok_hip_f16.so   bf16 = _Float16,  v_mfma_f32_*_f16 (the same rate), serves SETOK_F32 + SETOK_F16   (-DSETOK_HALF; round 6)
+// — the reference's inference loader and its non-bf16 launches run the tower in torch.float16 (src/model/builder.py:43,135-136,
+// src/train/train_setokim.py:326).  In the fp16 build the dtype code the sources compare against (SETOK_BF16) IS SETOK_F16, so that
+// library refuses bf16 buffers just as this one refuses fp16 ones.
+#ifdef SETOK_HALF
+typedef _Float16 bf16;
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
+#define SETOK_BF16 SETOK_F16
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -179,12 +197,19 @@ __device__ inline bool dropout_keep(unsigned long long seed, unsigned long long 
 
 
 // ---- LayerNorm folded into the consuming GEMM: the rank-2 start of the accumulators as two-way bf16 splits (gemm_persist.hip) ----------
+#ifdef SETOK_HALF
+__device__ inline void split2(float x, bf16& hi, bf16& lo) {           // fp16 build: x = hi + lo + O(2^-22 |x|), both by rounding (|x| < 65504: row means, 1 / rstd, column sums)
+    hi = (bf16)x;
+    lo = (bf16)(x - (float)hi);
+}
+#else
 __device__ inline void split2(float x, bf16& hi, bf16& lo) {           // x = hi + lo + O(2^-16 |x|), both by truncation
     const unsigned u = __builtin_bit_cast(unsigned, x);
     hi = __builtin_bit_cast(bf16, (unsigned short)(u >> 16));
     const float r = x - __builtin_bit_cast(float, u & 0xffff0000u);
     lo = __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r) >> 16));
 }
+#endif
 __device__ inline bf16x8 ln_col_frag(float c, float b) {                // the W-side operand's k-slots 0-7 for one output column
     bf16x8 f;
 #pragma unroll

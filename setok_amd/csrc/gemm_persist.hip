@@ -325,6 +325,17 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bw[e] = (bf16)0.0f;
                 if constexpr (!F32B) {
+#ifdef SETOK_HALF
+                    // fp16 build: three-way split by rounding — 33 bits of significand, exact for every bias whose parts stay normal (|b| < 65504; a part
+                    // below 2^-24 is dropped: an absolute error the fp16 output cannot hold); only the k-group-0 lanes carry it
+                    const float b = nb[j];
+                    const bf16 h1 = (bf16)b;
+                    const bool fin = __builtin_isfinite((float)h1);
+                    const float r1 = fin ? b - (float)h1 : 0.f;
+                    const bf16 h2 = (bf16)r1;
+                    const float r2 = r1 - (float)h2;
+                    if (g4 == 0) { bw[0] = h1; bw[1] = h2; bw[2] = (bf16)r2; }
+#else
                     // three-way exact split by truncation (top 16 bits of the fp32 pattern each time); only the k-group-0 lanes carry it
                     const float b = nb[j];
                     const float hi1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffff0000u);
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                         bw[1] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r1) >> 16)) : (bf16)0.0f;
                         bw[2] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16)) : (bf16)0.0f;
                     }
+#endif
                 }
                 f32x4 z;
 #pragma unroll
@@ -842,6 +854,12 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #define PP_POL_A PP_POLSTR(PP_PA)
 #define PP_POL_W PP_POLSTR(PP_PW)
 #define PP_POL_C PP_POLSTR(PP_PC)
+// PP_NT_STORE's inline-assembly stores carry hand-placed wait states for the gfx940+ "VALU write of the data registers of a > 64-bit store" hazard,
+// PP_MERGE_REM relies on s_barrier counting only the surviving waves of a workgroup, and the K loop on v_mfma_f32_16x16x32_bf16 / global_load_lds_dwordx4 /
+// one in-order vmcnt for loads and stores: all of it is gfx950 behaviour the compiler cannot check for another target.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gemm_persist.hip is written for gfx950 (MI355X) only: the hand-scheduled waits, hazards and barriers in it are not valid elsewhere"
+#endif
 #ifndef PP_RESYNC
 #define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
 #endif

@@ -284,7 +284,7 @@ class SetokDeTokenizer(PackCacheMixin, nn.Module):
         # tower's layer_norm1 / layer_norm2 are (ops.linear_ln: the GEMM streams the raw rows, a statistics pass replaces the LayerNorm's
         # read + write); SETOK_LN_FOLD=0 keeps the separate LayerNorm (A/B runs); the fp32 parity mode always does.
         D = self.decoder_embed_dim
-        if w.dtype == torch.bfloat16 and w.device.type == "cuda" and os.environ.get("SETOK_LN_FOLD", "1") != "0" and D % 64 == 0 \
+        if w.dtype in ops.LOW and w.device.type == "cuda" and os.environ.get("SETOK_LN_FOLD", "1") != "0" and D % 64 == 0 \
                 and all(b["fc1"][0].shape[0] % 64 == 0 for b in blocks):
             for b in blocks:
                 b["qkv_ln"] = ops.ln_fold(b["qkv"][0], b["n1"][0], b["n1"][1], b["qkv"][1])

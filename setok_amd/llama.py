@@ -140,12 +140,37 @@ def _refuse_unsupported_llama_fields(g) -> None:
         if kind not in (None, "default"):
             raise NotImplementedError(f"SetokimLlamaPrefill: {key}={rs!r} is not implemented on the HIP path (only the plain rotary "
                                       "embedding with `rope_theta`): a Llama-3.1-style checkpoint would give wrong logits")
+    _rope_theta(g)                                                          # (raises on two different values)
     hd, H, D = g("head_dim"), g("num_attention_heads"), g("hidden_size")
     if hd is not None and int(hd) != int(D) // int(H):
         raise NotImplementedError(f"SetokimLlamaPrefill: head_dim={hd} != hidden_size / num_attention_heads = {int(D) // int(H)} is not implemented")
     for k in ("attention_bias", "mlp_bias"):
         if g(k, False):
             raise NotImplementedError(f"SetokimLlamaPrefill: {k}=True is not implemented (the projections are loaded without a bias)")
+
+
+def _rope_theta(g) -> float:
+    """The rotary base.  Older HF configs carry it as the top-level `rope_theta`; newer ones keep it INSIDE `rope_parameters` (and some inside
+    `rope_scaling`) next to `rope_type: "default"`, which the guard above accepts — reading only the top-level field then silently used 10000
+    for a 500000-base checkpoint.  The dict's value wins when the top level has none; two different values are refused."""
+    top = g("rope_theta")
+    inner = None
+    for key in ("rope_parameters", "rope_scaling"):
+        rs = g(key)
+        if rs is None:
+            continue
+        v = rs.get("rope_theta") if isinstance(rs, dict) else getattr(rs, "rope_theta", None)
+        if v is None:
+            continue
+        if inner is not None and float(v) != float(inner):
+            raise NotImplementedError(f"SetokimLlamaPrefill: rope_parameters / rope_scaling carry two different rope_theta values ({inner} and {v})")
+        inner = v
+    if top is not None and inner is not None and float(top) != float(inner):
+        raise NotImplementedError(f"SetokimLlamaPrefill: rope_theta={top} at the top level of the config but {inner} inside rope_parameters: "
+                                  "refusing to pick one")
+    if inner is not None:
+        return float(inner)
+    return float(top) if top is not None else 10000.0
 
 
 class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
@@ -159,7 +184,7 @@ class SetokimLlamaPrefill(nn.Module, SetokimVisionMixin):
         self.config = config
         _refuse_unsupported_llama_fields(g)
         self.model = LlamaModel(g("vocab_size"), g("hidden_size"), g("intermediate_size"), g("num_hidden_layers"), g("num_attention_heads"),
-                                g("num_key_value_heads", g("num_attention_heads")), g("rms_norm_eps", 1e-5), g("rope_theta", 10000.0))
+                                g("num_key_value_heads", g("num_attention_heads")), g("rms_norm_eps", 1e-5), _rope_theta(g))
         self.lm_head = nn.Linear(g("hidden_size"), g("vocab_size"), bias=False)
         self.vision_tower = vision_tower
         self.mm_in_projector = mm_in_projector

@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, BF16, F32  # noqa: F401
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICK_GELU, BF16, F16, F32  # noqa: F401
 
 Tensor = torch.Tensor
 
@@ -20,7 +20,12 @@ def _code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
-    raise TypeError(f"setok_amd supports float32 and bfloat16, got {dt}")
+    if dt == torch.float16:
+        return F16                               # (a marked int: _lib.call sends the call to libsetok_hip_f16.so)
+    raise TypeError(f"setok_amd supports float32, bfloat16 and float16, got {dt}")
+
+
+LOW = (torch.bfloat16, torch.float16)            # the 16-bit element types: MFMA throughput mode, fp32 accumulation
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -53,40 +58,50 @@ def round_up(x: int, m: int) -> int:
 
 
 def k_align(dt: torch.dtype) -> int:
-    return 64 if dt == torch.bfloat16 else 16
+    return 64 if dt in LOW else 16
 
 
 # ---- optional launch profiler (bench.py): HIP events recorded INSIDE the library around every GEMM / clustering call ---------------------
 _ACT_NAMES = ("plain", "quick_gelu", "gelu_erf")
 
 
+def _profiled_libs():
+    """(half, lib) of the library builds this process has loaded: the profiler's state is per library."""
+    _lib.load()
+    return sorted(_lib._libs.items())
+
+
 def profile_start() -> None:
-    _lib.call("setok_profile_start")
+    for half, _ in _profiled_libs():
+        _lib.call("setok_profile_start", half=half)
 
 
 def profile_pause(pause: bool = True) -> None:
     """Between profile_start() and profile_stop(): stop (True) / resume (False) attaching events to launches; what was recorded stays."""
-    _lib.call("setok_profile_pause", 1 if pause else 0)
+    for half, _ in _profiled_libs():
+        _lib.call("setok_profile_pause", 1 if pause else 0, half=half)
 
 
 def profile_stop():
     """Synchronise and return [{kernel, flops, ms, bytes}] for every launch the library recorded since profile_start()."""
     import numpy as np
     cap = 1 << 16
-    kind, cls = np.empty(cap, np.int32), np.empty(cap, np.int32)
-    work, nbytes, ms = np.empty(cap, np.float64), np.empty(cap, np.float64), np.empty(cap, np.float32)
-    n = _lib.load().setok_profile_stop(kind.ctypes.data, cls.ctypes.data, work.ctypes.data, nbytes.ctypes.data, ms.ctypes.data, cap)
-    if n < 0:
-        raise _lib.SetokHipError("setok_profile_stop failed")
     out = []
-    for i in range(n):
-        if kind[i] == 2:
-            name, w = "cluster_dpc_knn", float(nbytes[i])            # the clustering record's headline quantity is algorithmic BYTES
-        else:
-            c = int(cls[i])
-            name = ("gemm_bf16:" if kind[i] == 0 else "gemm_f32:") + _ACT_NAMES[c & 3] + ("+residual" if c & 4 else "") + ("+layernorm" if c & 8 else "")
-            w = float(work[i])
-        out.append(dict(kernel=name, flops=w, ms=float(ms[i]), bytes=float(nbytes[i])))
+    for half, lib in _profiled_libs():
+        kind, cls = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        work, nbytes, ms = np.empty(cap, np.float64), np.empty(cap, np.float64), np.empty(cap, np.float32)
+        n = lib.setok_profile_stop(kind.ctypes.data, cls.ctypes.data, work.ctypes.data, nbytes.ctypes.data, ms.ctypes.data, cap)
+        if n < 0:
+            raise _lib.SetokHipError("setok_profile_stop failed")
+        low = "gemm_f16:" if half else "gemm_bf16:"
+        for i in range(n):
+            if kind[i] == 2:
+                name, w = "cluster_dpc_knn", float(nbytes[i])            # the clustering record's headline quantity is algorithmic BYTES
+            else:
+                c = int(cls[i])
+                name = (low if kind[i] == 0 else "gemm_f32:") + _ACT_NAMES[c & 3] + ("+residual" if c & 4 else "") + ("+layernorm" if c & 8 else "")
+                w = float(work[i])
+            out.append(dict(kernel=name, flops=w, ms=float(ms[i]), bytes=float(nbytes[i])))
     return out
 
 
@@ -129,13 +144,14 @@ def row_stats(x: Tensor, eps: float = 1e-5, out: Optional[Tensor] = None) -> Ten
 
 def ln_fold(w: Tensor, gamma: Tensor, beta: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """Once per weight load: (W' = bf16(gamma * W), c = W' 1, b' = b + W beta, the (N, 4)-word MFMA fragments of (c, b')) for linear_ln."""
-    assert w.dtype == torch.bfloat16 and w.dim() == 2
+    assert w.dtype in LOW and w.dim() == 2
     N, K = w.shape
     wg = torch.empty_like(w)
     cs = torch.empty((N,), dtype=torch.float32, device=w.device)
     bf = torch.empty((N,), dtype=torch.float32, device=w.device)
     fr = torch.empty((N, 4), dtype=torch.float32, device=w.device)
-    _lib.call("setok_ln_fold", _stream(), _p(w.contiguous()), _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(bias)), _p(wg), _p(cs), _p(bf), _p(fr), N, K)
+    _lib.call("setok_ln_fold", _stream(), _p(w.contiguous()), _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(bias)), _p(wg), _p(cs), _p(bf), _p(fr), N, K,
+              half=w.dtype == torch.float16)
     return wg, cs, bf, fr
 
 
@@ -144,10 +160,10 @@ def linear_ln(a: Tensor, folded: Tuple[Tensor, Tensor, Tensor, Tensor], stats: T
     wg, _, _, fr = folded
     M, K = a.shape
     N = wg.shape[0]
-    assert a.dtype == torch.bfloat16 and wg.shape[1] == K and stats.shape == (M, 8)
+    assert a.dtype in LOW and wg.dtype == a.dtype and wg.shape[1] == K and stats.shape == (M, 8)
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    _lib.call("setok_linear_ln", _stream(), _p(a), K, _p(wg), _p(fr), _p(stats), _p(out), N, M, N, K, act)
+    _lib.call("setok_linear_ln", _stream(), _p(a), K, _p(wg), _p(fr), _p(stats), _p(out), N, M, N, K, act, half=a.dtype == torch.float16)
     return out
 
 

@@ -29,7 +29,7 @@ HEAD_MODULES = ("out", "inter_encoder", "inner_encoder")          # the order th
 
 
 def _k_granule(dtype) -> int:
-    return 64 if dtype == torch.bfloat16 else 16                  # contraction granule of setok_linear
+    return 64 if dtype in (torch.bfloat16, torch.float16) else 16                  # contraction granule of setok_linear
 
 
 # ----------------------------------------------------------------------------------------------------------------------------

@@ -314,8 +314,10 @@ def gen_head_grads():
 
 
 # ----------------------------------------------------------------------------------------------
-def gen_bf16_reference():
-    """The bf16 throughput mode's yardstick: the REFERENCE's own head cast to torch.bfloat16 (what train_setokim.py:326 does to the whole tower
+def gen_bf16_reference(dt=torch.bfloat16, name="bf16_reference"):
+    """(dt = torch.float16, name = "fp16_reference": the same yardstick for the fp16 mode, round 6 — the reference's inference loader casts the
+    tower to torch.float16, src/model/builder.py:43,135-136.)
+    The bf16 throughput mode's yardstick: the REFERENCE's own head cast to torch.bfloat16 (what train_setokim.py:326 does to the whole tower
     module) run on CPU from fixed bf16 features — the reference's fp32 tower features of vitl_224.npz / vitl_336.npz rounded to bf16 — and, per
     stage, its distance from the fp32 oracle evaluated on the SAME bf16-valued inputs (x after the positional add, the bf16-rounded weights) and the
     SAME cluster assignment.  A GPU bf16 result is held to <= 1.5 x these distances (tests/test_fullsize_gpu.py).  Stored per image: the
@@ -323,19 +325,20 @@ def gen_bf16_reference():
     features (the reference's bf16 clustering rounds its scores to bf16 and may pick a different L)."""
     hc = O.HeadConfig(threshold=0.125)
     hsd = O.init_head_weights(hc, seed=1)
-    hsd_b = {k: v.bfloat16().float() for k, v in hsd.items()}
+    hsd_b = {k: v.to(dt).float() for k, v in hsd.items()}
     d = R.make_clip_dir(1024, 1, 16, 4096, 224, 14, seed=0)            # a 1-layer stand-in tower: only the head is exercised
     tok = R.build_reference_tokenizer(d, hidden_dim=1024, token_feat_dim=4096, dim_feedforward=4096, min_cluster_num=64, threshold=0.125,
                                       select_layer=-2)
     res = tok.load_state_dict(hsd, strict=False)
     assert not res.unexpected_keys
-    tok = tok.to(torch.bfloat16)
+    tok = tok.to(dt)
+    low = "bf16" if dt == torch.bfloat16 else "fp16"
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
     arrs = {}
     for cfg, src in (("cfg2", "vitl_224"), ("cfg4", "vitl_336")):
         feats = torch.from_numpy(np.load(os.path.join(HERE, src + ".npz"))["feats"])
         for i in range(feats.shape[0]):
-            r = R.rac_head_single(tok, feats[i].bfloat16(), return_stages=True)
+            r = R.rac_head_single(tok, feats[i].to(dt), return_stages=True)
             x, lab = r["x"].float(), r["idx_cluster"]
             group = O.group_encoding(hsd_b, hc, x, lab)
             inter = O.block_forward(hsd_b, "inter_encoder.", group, hc.nheads, hc.intra_cluster_layers)
@@ -348,9 +351,9 @@ def gen_bf16_reference():
             arrs[pre + "L"] = np.array([r["tokens"].shape[0], f32.index_down.numel()])
             if cfg == "cfg2":
                 arrs[pre + "tokens"] = npy(r["tokens"].float())
-            print(f"  {cfg}/img{i}: reference-bf16 L = {r['tokens'].shape[0]} (fp32 clustering of the same features: {f32.index_down.numel()}); "
-                  f"reference-bf16 vs fp32 oracle: group {errs[0]:.3e} inter {errs[1]:.3e} tokens {errs[2]:.3e}")
-    save("bf16_reference", **arrs)
+            print(f"  {cfg}/img{i}: reference-{low} L = {r['tokens'].shape[0]} (fp32 clustering of the same features: {f32.index_down.numel()}); "
+                  f"reference-{low} vs fp32 oracle: group {errs[0]:.3e} inter {errs[1]:.3e} tokens {errs[2]:.3e}")
+    save(name, **arrs)
 
 
 def partition_drift(index_down_a, idx_a, index_down_b, idx_b):
@@ -362,8 +365,10 @@ def partition_drift(index_down_a, idx_a, index_down_b, idx_b):
     return abs(len(a) - len(b)), 1.0 - jacc, 1.0 - same
 
 
-def gen_bf16_tower():
-    """VERDICT r03 item 5 — the throughput mode's yardstick FROM PIXELS: the reference's own tower (HF CLIPVisionModel behind the reference's
+def gen_bf16_tower(dt=torch.bfloat16, name="bf16_tower"):
+    """(dt = torch.float16, name = "fp16_tower": the fp16 mode's yardstick, round 6; its keys say `lowbits` where the bf16 fixture says `bf16_bits`,
+    and the ViT-L feature bits are not stored — errors and drifts only.)
+    VERDICT r03 item 5 — the throughput mode's yardstick FROM PIXELS: the reference's own tower (HF CLIPVisionModel behind the reference's
     CLIPVisionTower) AND head, cast to torch.bfloat16 as train_setokim.py:326 casts the module, run on CPU on the images of vitl_224.npz
     (ViT-L/14-224, seeds 0 / 1 / 3) and of e2e_small.npz's recipe; stored: the reference-bf16 tower features (bf16 bit patterns), their
     distance from the reference's fp32 features, and how far the reference's bf16 clustering drifts from its fp32 clustering (token count,
@@ -371,6 +376,8 @@ def gen_bf16_tower():
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
     rms = lambda a, b: float(((a.double() - b.double()) ** 2).mean().sqrt() / (b.double() ** 2).mean().sqrt())
     arrs = {}
+    is_bf = dt == torch.bfloat16
+    low, bits_key = ("bf16", "feats_bf16_bits") if is_bf else ("fp16", "feats_lowbits")
     # ---- ViT-L/14-224, 2 images (the inputs and fp32 outputs of vitl_224.npz) ----------------------------------------------------------
     vc, hc = O.VitConfig(), O.HeadConfig(threshold=0.125)
     tsd, hsd = O.init_tower_weights(vc, seed=0), O.init_head_weights(hc, seed=1)
@@ -388,21 +395,23 @@ def gen_bf16_tower():
                                                 idx_cluster=torch.from_numpy(z[f"{i}:idx_cluster"]).long()) for i in range(2)]
         else:                                                        # the launch scripts' layer selection: fp32 run here, features stored too
             f32_feats, f32_res = R.rac_forward(tok, images, noise=None, return_stages=True)
-            arrs["vitl:sel-1:feats32"] = npy(f32_feats)
-            for i, r in enumerate(f32_res):
-                arrs[f"vitl:sel-1:{i}:index_down32"] = npy(r["index_down"]).astype(np.int32)
-                arrs[f"vitl:sel-1:{i}:idx_cluster32"] = npy(r["idx_cluster"]).astype(np.int32)
-        tok_b = tok.to(torch.bfloat16)
-        feats_b, res_b = R.rac_forward(tok_b, images.bfloat16(), noise=None, return_stages=True)
+            if is_bf:                                                # (the fp16 fixture reads the fp32 run of select_layer = -1 from bf16_tower.npz)
+                arrs["vitl:sel-1:feats32"] = npy(f32_feats)
+                for i, r in enumerate(f32_res):
+                    arrs[f"vitl:sel-1:{i}:index_down32"] = npy(r["index_down"]).astype(np.int32)
+                    arrs[f"vitl:sel-1:{i}:idx_cluster32"] = npy(r["idx_cluster"]).astype(np.int32)
+        tok_b = tok.to(dt)
+        feats_b, res_b = R.rac_forward(tok_b, images.to(dt), noise=None, return_stages=True)
         tag = f"vitl:sel{sel}"
-        arrs[tag + ":feats_bf16_bits"] = npy(feats_b.view(torch.int16))
+        if is_bf:
+            arrs[tag + ":feats_bf16_bits"] = npy(feats_b.view(torch.int16))
         arrs[tag + ":tower_err"] = np.array([rel(feats_b.float(), f32_feats), rms(feats_b.float(), f32_feats)])
-        print(f"  {tag}: reference-bf16 tower vs its fp32 tower: max-rel {rel(feats_b.float(), f32_feats):.3e}  rms-rel {rms(feats_b.float(), f32_feats):.3e}")
+        print(f"  {tag}: reference-{low} tower vs its fp32 tower: max-rel {rel(feats_b.float(), f32_feats):.3e}  rms-rel {rms(feats_b.float(), f32_feats):.3e}")
         for i, r in enumerate(res_b):
             dl, dj, dp = partition_drift(r["index_down"], r["idx_cluster"], f32_res[i]["index_down"], f32_res[i]["idx_cluster"])
             arrs[f"{tag}:{i}:drift"] = np.array([dl, dj, dp])
             arrs[f"{tag}:{i}:L"] = np.array([r["index_down"].numel(), f32_res[i]["index_down"].numel()])
-            print(f"  {tag}/img{i}: reference-bf16 L = {r['index_down'].numel()} (its fp32 run: {f32_res[i]['index_down'].numel()}); "
+            print(f"  {tag}/img{i}: reference-{low} L = {r['index_down'].numel()} (its fp32 run: {f32_res[i]['index_down'].numel()}); "
                   f"1 - centre Jaccard {dj:.3f}; tokens with another centre {dp:.3f}")
     # ---- small dims, the whole path (the tower of e2e_small's recipe), 4 images --------------------------------------------------------
     tok = small_tok(sel=-2)
@@ -416,13 +425,23 @@ def gen_bf16_tower():
     arrs["small:w_keys"] = np.array(sorted(tok.state_dict().keys()))
     for k_, v_ in tok.state_dict().items():
         arrs["small:w:" + k_] = npy(v_)
-    tok_b = tok.to(torch.bfloat16)
-    feats_b, res_b = R.rac_forward(tok_b, images.bfloat16(), threshold=thr, noise=None, return_stages=True)
+    tok_b = tok.to(dt)
+    feats_b, res_b = R.rac_forward(tok_b, images.to(dt), threshold=thr, noise=None, return_stages=True)
     arrs["small:feats32"] = npy(f32_feats)
-    arrs["small:feats_bf16_bits"] = npy(feats_b.view(torch.int16))
+    arrs["small:" + bits_key] = npy(feats_b.view(torch.int16))
     arrs["small:tower_err"] = np.array([rel(feats_b.float(), f32_feats), rms(feats_b.float(), f32_feats)])
-    print(f"  small: reference-bf16 tower vs fp32: max-rel {rel(feats_b.float(), f32_feats):.3e}  rms-rel {rms(feats_b.float(), f32_feats):.3e}")
-    save("bf16_tower", **arrs)
+    if not is_bf:                                                    # the whole path at small dims in fp16: the reference's tokens and its clustering drift from fp32
+        for i, (rb, r32) in enumerate(zip(res_b, f32_res)):
+            dl, dj, dp = partition_drift(rb["index_down"], rb["idx_cluster"], r32["index_down"], r32["idx_cluster"])
+            arrs[f"small:{i}:drift"] = np.array([dl, dj, dp])
+            arrs[f"small:{i}:L"] = np.array([rb["index_down"].numel(), r32["index_down"].numel()])
+            arrs[f"small:{i}:tokens32"] = npy(r32["tokens"])
+            arrs[f"small:{i}:idx_cluster32"] = npy(r32["idx_cluster"]).astype(np.int32)
+            if rb["tokens"].shape == r32["tokens"].shape:
+                arrs[f"small:{i}:tokens_err"] = np.array([rel(rb["tokens"].float(), r32["tokens"]), rms(rb["tokens"].float(), r32["tokens"])])
+            print(f"  small/img{i}: reference-{low} L = {rb['index_down'].numel()} (fp32 {r32['index_down'].numel()}), drift {dl} {dj:.3f} {dp:.3f}")
+    print(f"  small: reference-{low} tower vs fp32: max-rel {rel(feats_b.float(), f32_feats):.3e}  rms-rel {rms(feats_b.float(), f32_feats):.3e}")
+    save(name, **arrs)
 
 
 STAGE2_CASES = {
@@ -571,6 +590,10 @@ if __name__ == "__main__":
         gen_bf16_reference()
     if "bf16_tower" in which:
         gen_bf16_tower()
+    if "fp16_reference" in which:
+        gen_bf16_reference(torch.float16, "fp16_reference")
+    if "fp16_tower" in which:
+        gen_bf16_tower(torch.float16, "fp16_tower")
     if "detok" in which:
         gen_detok()
     if "splice" in which:

@@ -209,6 +209,14 @@ def test_llama_prefill_refuses_config_fields_it_would_silently_ignore():
         with pytest.raises(NotImplementedError):
             SetokimLlamaPrefill(dict(base, **bad))
 
+    # newer HF configs keep the rotary base INSIDE rope_parameters; it must be read from there, and a conflict refused
+    no_top = {k: v for k, v in base.items() if k != "rope_theta"}
+    assert SetokimLlamaPrefill(dict(no_top, rope_parameters={"rope_type": "default", "rope_theta": 500000.0})).model.rope_theta == 500000.0
+    assert SetokimLlamaPrefill(dict(base, rope_parameters={"rope_type": "default", "rope_theta": 10000.0})).model.rope_theta == 10000.0
+    assert SetokimLlamaPrefill(dict(no_top)).model.rope_theta == 10000.0
+    with pytest.raises(NotImplementedError):
+        SetokimLlamaPrefill(dict(base, rope_parameters={"rope_type": "default", "rope_theta": 500000.0}))
+
     class Cfg:                                                                               # attribute-style configs (HF) are read the same way
         pass
     c = Cfg()
