@@ -317,6 +317,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    numa = {}
+    if world > 1 and not args.share_gpu:
+        from setok_amd.parallel import pin_host_to_gpu_numa_node
+        numa = pin_host_to_gpu_numa_node(local)                     # this rank's host threads next to its GPU (best effort; reported per rank)
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -400,6 +404,7 @@ def main():
         out = step()
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
+    startup_s = time.perf_counter() - T_START                       # process start -> model built, context warm, warm-up steps done: what a rank spends before the barrier
     barrier()
     ops.profile_start()                          # HIP events around every GEMM launch, on the launch stream ...
     pe = max(1, args.probe_every)                # ... of every pe-th timed step: the probe has a cost of its own (see --probe-every)
@@ -418,7 +423,8 @@ def main():
     dt = max_over_ranks(dt_local, device=dev)            # wall time of the slowest rank
 
     counts = out.counts
-    mine = dict(rank=rank, ms_per_step=round(dt_local / args.steps * 1e3, 3), tokens_per_image=round(sum(counts) / len(counts), 2))
+    mine = dict(rank=rank, ms_per_step=round(dt_local / args.steps * 1e3, 3), tokens_per_image=round(sum(counts) / len(counts), 2),
+                startup_s=round(startup_s, 1), **({"numa_node": numa.get("numa_node"), "host_cpus": numa.get("cpus")} if numa else {}))
     if trainer is not None:
         mine.update(trainer.comm_stats())
     per_rank = [mine]

@@ -36,6 +36,9 @@ int cu_count() {                       // of the CURRENT device
 #ifndef ATTN_O_SWAP
 #define ATTN_O_SWAP 1
 #endif
+#ifndef ATTN_SHORT_TAIL
+#define ATTN_SHORT_TAIL 1     // 1 (round 6): a last key tile with at most 8 valid keys (T = 257 / 577: ONE — every ViT with a class token; T = 197: 5) runs a short form of
+#endif                        // the softmax step — 4 of the 16 score registers, one of the two PV k-steps — instead of exponentiating 15 masked scores per lane
 constexpr int ROWB = 128;              // bytes per K / V row in LDS: 64 dims; a 48-dim head leaves two 16-byte slots of each row unused
 
 typedef __attribute__((ext_vector_type(4))) short short4v;
@@ -199,6 +202,47 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             float t[16];
             float mx = -INFINITY;
             const bool tail = (kt == nkv - 1) && (Tp != T);
+#if ATTN_SHORT_TAIL
+            if (tail && T - kt * 32 <= 8) {               // (wave-uniform)
+                // The tile's valid keys are kt * 32 + r + 4 hi, r = 0 .. 3 (registers 0-3 of the score tile): the other twelve registers hold masked scores whose
+                // probabilities are exactly 0 — the general form below exponentiates them, adds the zeros to the row sum and multiplies V's rows 16-31 by them.
+                // Same operations in the same order on the four live registers, so the bits do not change: 9 of a T = 257 query tile's 81 (tile, tile) units
+                // cost a quarter of the vector instructions and 6 instead of 8 MFMAs.
+                const int nvalid = T - kt * 32;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { t[r] = (r + 4 * hi < nvalid) ? s[r] : -INFINITY; mx = fmaxf(mx, t[r]); }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);
+                if (!__all(m_new == m_run)) {
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                    m_run = m_new;
+                }
+                const float mc = m_run * scale_log2e;
+                float ls = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { t[r] = __builtin_amdgcn_exp2f(fmaf(t[r], scale_log2e, -mc)); ls += t[r]; }
+                l_run += ls;
+#pragma unroll
+                for (int r = 4; r < 8; ++r) t[r] = 0.f;
+                const bf16x8 p0 = pack8(t);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const char* vb = Vs + (kt * 32 + tr_row) * ROWB + (d * 32 + tr_col) * 2;
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb));
+                    const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vb + 8 * ROWB));
+                    union { short s8[8]; bf16x8 v; } u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { u.s8[j] = lo[j]; u.s8[4 + j] = hi4[j]; }
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, p0, o[d], 0, 0, 0);
+                }
+                continue;
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 t[r] = s[r];

@@ -854,6 +854,10 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #define PP_POL_A PP_POLSTR(PP_PA)
 #define PP_POL_W PP_POLSTR(PP_PW)
 #define PP_POL_C PP_POLSTR(PP_PC)
+#ifndef PP_PC_RES
+#define PP_PC_RES PP_PC     // the same for the launches with a residual (proj / fc2: 135 MB of output per launch against 404 / 539 MB — the one class write-through stores did not slow down)
+#endif
+#define PP_POL_C_RES PP_POLSTR(PP_PC_RES)
 // PP_NT_STORE's inline-assembly stores carry hand-placed wait states for the gfx940+ "VALU write of the data registers of a > 64-bit store" hazard,
 // PP_MERGE_REM relies on s_barrier counting only the surviving waves of a workgroup, and the K loop on v_mfma_f32_16x16x32_bf16 / global_load_lds_dwordx4 /
 // one in-order vmcnt for loads and stores: all of it is gfx950 behaviour the compiler cannot check for another target.
@@ -1330,7 +1334,10 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                             // (s_nop 1: a VALU write of the data registers of a > 64-bit store needs two wait states behind it on gfx940+ — the compiler's hazard
                             //  recognizer pads its own stores, it cannot know that this statement is one: without the pad the erf-GELU instantiation, which reuses
                             //  the registers at once, stored the next element's intermediates — profiles/r05_nt_store_hazard.log)
-                            asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
+                            if constexpr (RESK)
+                                asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C_RES "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
+                            else
+                                asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
                         } else
 #endif
                         *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];

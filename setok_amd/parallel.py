@@ -135,6 +135,37 @@ class GradBuckets:
         return len(self.flat[mod])
 
 
+def pin_host_to_gpu_numa_node(local_gpu: int) -> dict:
+    """One process per GPU: keep this rank's host threads (the launcher of ~200 kernels per step, the RCCL proxy thread) on the CPU socket its
+    GPU hangs off — on an 8-GPU node eight unpinned ranks migrate between sockets and launch across the inter-socket link.  Best effort and
+    silent: reads the GPU's PCI address from HIP, its `numa_node` and that node's `cpulist` from sysfs, and restricts the process to the
+    intersection with the CPUs it is already allowed (a launcher's own pinning is respected).  Returns what it did for the bench record."""
+    import os
+    info = {"numa_node": None, "cpus": None}
+    try:
+        bus = torch.cuda.get_device_properties(local_gpu).pci_bus_id
+        dev_id = torch.cuda.get_device_properties(local_gpu).pci_device_id
+        dom = getattr(torch.cuda.get_device_properties(local_gpu), "pci_domain_id", 0)
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev_id:02x}.0/numa_node"
+        with open(path) as f:
+            node = int(f.read().strip())
+        info["numa_node"] = node
+        if node < 0:
+            return info
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            info["cpus"] = len(allowed)
+    except Exception:                                               # no sysfs, a container without the node files, a non-Linux host: leave the scheduler alone
+        pass
+    return info
+
+
 def max_over_ranks(seconds: float, device=None, group=None) -> float:
     """The benchmark's timing rule: wall time of the slowest rank."""
     if not (dist.is_available() and dist.is_initialized()):

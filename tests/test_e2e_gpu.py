@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity
 import setok_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -58,9 +59,9 @@ def test_head_small_golden(golden_dir, case):
     assert torch.equal(st["index_down"][0, :L].cpu(), _t(z[f"{case}:index_down"]))
     assert torch.equal(idx[0].cpu(), _t(z[f"{case}:idx_cluster"]))
     assert idx.dtype == torch.int64 and tuple(score.shape) == (1, 1, N) and tuple(toks[0].shape) == (L, 96)
-    assert _rel(st["group"], _t(z[f"{case}:group"])) < TOL
-    assert _rel(st["inter"], _t(z[f"{case}:inter"])) < TOL
-    assert _rel(toks[0], _t(z[f"{case}:tokens"])) < TOL
+    parity.close(st["group"], _t(z[f"{case}:group"]), TOL, "st['group'], _t(z[f'{case}:group'])")
+    parity.close(st["inter"], _t(z[f"{case}:inter"]), TOL, "st['inter'], _t(z[f'{case}:inter'])")
+    parity.close(toks[0], _t(z[f"{case}:tokens"]), TOL, "toks[0], _t(z[f'{case}:tokens'])")
 
 
 @pytest.mark.parametrize("tag", ["sel-2_fallback", "sel-2_dynamic", "sel-1_fallback", "sel-1_dynamic"])
@@ -72,13 +73,13 @@ def test_e2e_small_golden(golden_dir, tag):
     images, noise = _t(z["images"]), _t(z["noise"])
     thr = float(z[f"{tag}:threshold"])
     feats = tok.image_feature_encoder(images.to(DEV))
-    assert _rel(feats, _t(z[f"{tag}:feats"])) < 2e-5
+    parity.close(feats, _t(z[f"{tag}:feats"]), 2e-5, "feats, _t(z[f'{tag}:feats'])")
     toks, idx, score = tok(images.to(DEV), threshold=thr, noise=noise)
     assert len(toks) == images.shape[0]
     for i in range(images.shape[0]):
         assert torch.equal(idx[i].cpu(), _t(z[f"{tag}:{i}:idx_cluster"])), (tag, i)
         assert toks[i].shape[0] == _t(z[f"{tag}:{i}:index_down"]).numel()
-        assert _rel(toks[i], _t(z[f"{tag}:{i}:tokens"])) < TOL
+        parity.close(toks[i], _t(z[f"{tag}:{i}:tokens"]), TOL, "toks[i], _t(z[f'{tag}:{i}:tokens'])")
     # list input == batched input (clip_encoder.py:52-57)
     toks_l, idx_l, _ = tok([im for im in images.to(DEV)], threshold=thr, noise=noise)
     assert torch.equal(idx_l, idx) and torch.equal(toks_l.packed, toks.packed)
@@ -109,12 +110,12 @@ def test_vitl_head_from_reference_features(golden_dir):
         stats = O.check_cluster_parity(st["index_down"][i, :L].cpu(), idx[i].cpu(), _t(z[f"{i}:index_down"]).long(),
                                        _t(z[f"{i}:idx_cluster"]).long(), sens)
         assert sens["centres_certain"] and stats["tokens_equal"] == 256          # bit-exact indices and token count
-        assert _rel(toks[i], _t(z[f"{i}:tokens"])) < TOL
+        parity.close(toks[i], _t(z[f"{i}:tokens"]), TOL, "toks[i], _t(z[f'{i}:tokens'])")
     start = 0
     for i in range(2):
         L = st["counts"][i]
         if bool((idx[i].cpu() == _t(z[f"{i}:idx_cluster"]).long()).all()):
-            assert _rel(st["group"][start:start + L], _t(z[f"{i}:group"])) < TOL
+            parity.close(st["group"][start:start + L], _t(z[f"{i}:group"]), TOL, "st['group'][start:start + L], _t(z[f'{i}:group'])")
         start += L
 
 
@@ -126,7 +127,7 @@ def test_vitl_tower_fp32_parity(golden_dir):
     images = torch.randn(2, 3, 224, 224, generator=g)
     feats = tok.image_feature_encoder(images.to(DEV))
     assert tuple(feats.shape) == (2, 256, 1024)
-    assert _rel(feats, _t(z["feats"])) < TOL
+    parity.close(feats, _t(z["feats"]), TOL, "feats, _t(z['feats'])")
     # and the whole path from pixels: counts/indices equal unless the fp64 margin analysis calls them fragile
     toks, idx, score = tok(images.to(DEV))
     x = _t(z["feats"]) + O.pos_encoding_2d(16, 16, 1024)[None]
@@ -181,7 +182,7 @@ def test_encode_images_and_projector():
         assert len(out) == 3
         for i in range(3):
             assert out[i].shape == ref[i].shape
-            assert _rel(out[i], ref[i]) < TOL, ptype
+            parity.close(out[i], ref[i], TOL, "out[i], ref[i]")
 
 
 def test_boundary_errors_and_attributes():
@@ -224,7 +225,7 @@ def test_336_input_576_patches(dt, tol):
     feats = tok.image_feature_encoder(images.to(DEV)).float().cpu()
     feats_ref, ref = O.encode(sd, vc, hc, images)
     assert tuple(feats.shape) == (2, 576, 128)
-    assert _rel(feats, feats_ref) < tol
+    parity.close(feats, feats_ref, tol, "feats, feats_ref")
     toks, idx, score = tok(images.to(DEV))
     assert tuple(idx.shape) == (2, 576) and tuple(score.shape) == (2, 1, 576)
     for i in range(2):
@@ -234,7 +235,7 @@ def test_336_input_576_patches(dt, tol):
             assert sens["centres_certain"] and bool(sens["assign_certain"].all())       # seeded inputs chosen so: no vacuous pass
             same = idx[i].cpu() == ref[i].idx_cluster
             assert bool(same.all())
-            assert _rel(toks[i], ref[i].tokens) < TOL
+            parity.close(toks[i], ref[i].tokens, TOL, "toks[i], ref[i].tokens")
 
 
 def test_full_size_batch_invariance_and_properties():
@@ -298,7 +299,7 @@ def test_cfg1_vitb16_fixed_k32_fp32():
     toks, idx, score = tok(image.to(DEV))
     feats_ref, ref = O.encode(sd, vc, hc, image)
     assert toks[0].shape == (32, 4096) and ref[0].tokens.shape == (32, 4096) and tuple(idx.shape) == (1, 196)
-    assert _rel(tok.image_feature_encoder(image.to(DEV)), feats_ref) < TOL
+    parity.close(tok.image_feature_encoder(image.to(DEV)), feats_ref, TOL, "tok.image_feature_encoder(image.to(DEV)), feats_ref")
     x = feats_ref[0] + O.pos_encoding_2d(14, 14, 768)
     sens = O.cluster_sensitivity(x, 32, 1e9, 32, ulps=256.0)
     same = idx[0].cpu() == ref[0].idx_cluster
@@ -306,5 +307,5 @@ def test_cfg1_vitb16_fixed_k32_fp32():
     assert sens["centres_certain"] and float(sens["assign_certain"].float().mean()) >= 0.97
     assert bool((same | ~sens["assign_certain"]).all())
     if bool(same.all()):
-        assert _rel(toks[0], ref[0].tokens) < TOL
+        parity.close(toks[0], ref[0].tokens, TOL, "toks[0], ref[0].tokens")
     print("cfg1 ViT-B/16 k=32: tokens with a different cluster id:", int((~same).sum()), "of 196; centres certain:", bool(sens["centres_certain"]))

@@ -234,8 +234,8 @@ def test_fp16_encode_is_deterministic_and_graph_replay_equals_eager():
 def test_projector_in_fp16():
     """encode_images' second half (setokim_arch.py:206-211, multimodal_projector/builder.py:33-59) on float16 tokens: mlp2x_gelu vs fp64 torch."""
     from setok_amd.builder import build_vision_projector
-    proj = build_vision_projector("mlp2x_gelu", mm_hidden_size=96, hidden_size=128).to(DEV, H).eval()
-    x = _rand(37, 96, seed=3).to(H)
+    proj = build_vision_projector("mlp2x_gelu", mm_hidden_size=128, hidden_size=192).to(DEV, H).eval()
+    x = _rand(37, 128, seed=3).to(H)
     with torch.no_grad():
         y = proj(x.to(DEV))
     lin = [m for m in proj.modules() if isinstance(m, torch.nn.Linear)]

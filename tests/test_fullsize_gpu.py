@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity
 import setok_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -271,8 +272,8 @@ def test_cfg4_vitl336_head_fp32_from_reference_features(golden_dir):
         assert sens["centres_certain"] and stats["tokens_equal"] == 576          # bit-exact indices and token count (fixture: all certain)
         assert L == _t(z[f"{i}:index_down"]).numel()
         O.check_score(score[i].cpu(), sens)
-        assert _rel(st["group"][start:start + L], _t(z[f"{i}:group"])) < TOL
-        assert _rel(toks[i], _t(z[f"{i}:tokens"])) < TOL
+        parity.close(st["group"][start:start + L], _t(z[f"{i}:group"]), TOL, "st['group'][start:start + L], _t(z[f'{i}:group'])")
+        parity.close(toks[i], _t(z[f"{i}:tokens"]), TOL, "toks[i], _t(z[f'{i}:tokens'])")
         start += L
 
 
@@ -302,7 +303,7 @@ def test_cfg4_vitl336_tower_fp32_and_whole_path_from_pixels(golden_dir):
             assert bool((same | ~sens["assign_certain"]).all())
             compared += int(sens["assign_certain"].sum())
             if bool(same.all()):
-                assert _rel(toks[i], _t(z[f"{i}:tokens"])) < TOL
+                parity.close(toks[i], _t(z[f"{i}:tokens"]), TOL, "toks[i], _t(z[f'{i}:tokens'])")
     print(f"cfg4 fp32 from pixels: tower rel err {ferr:.2e}; images with certain centres {certain}/2; certain assignments compared {compared}/1152; "
           f"tokens with a different cluster id {n_diff}")
     assert certain == 2 and compared >= 0.97 * 1152                              # the fixture's decisions are certain: no vacuous pass
@@ -375,16 +376,16 @@ def test_cfg5_vicuna7b_dims_two_layers_fp32_vs_hf(golden_dir):
     del sd
     hidden = m.model(x.to(DEV), am.to(DEV), pos.to(DEV))
     v = am.bool()
-    assert _rel(hidden.cpu()[v], _t(z["hidden"])[v]) < TOL
+    parity.close(hidden.cpu()[v], _t(z["hidden"])[v], TOL, "hidden.cpu()[v], _t(z['hidden'])[v]")
     lg, _, _ = m(inputs_embeds=x.to(DEV), attention_mask=am.to(DEV), position_ids=pos.to(DEV))
     assert tuple(lg.shape) == (B, T, 32000)
     stride = 32000 // _t(z["logits_cols"]).shape[-1] + 1
-    assert _rel(lg.cpu()[:, :, ::stride][v], _t(z["logits_cols"])[v]) < TOL
+    parity.close(lg.cpu()[:, :, ::stride][v], _t(z["logits_cols"])[v], TOL, "lg.cpu()[:, :, ::stride][v], _t(z['logits_cols'])[v]")
     last = _t(z["last"]).tolist()
     got_last = torch.stack([lg[b, t] for b, t in enumerate(last)]).cpu()
-    assert _rel(got_last, _t(z["logits_last"])) < TOL
+    parity.close(got_last, _t(z["logits_last"]), TOL, "got_last, _t(z['logits_last'])")
     only_last, _, _ = m(inputs_embeds=x.to(DEV), attention_mask=am.to(DEV), position_ids=pos.to(DEV), last_token_only=True)
-    assert _rel(only_last.cpu(), _t(z["logits_last"])) < TOL
+    parity.close(only_last.cpu(), _t(z["logits_last"]), TOL, "only_last.cpu(), _t(z['logits_last'])")
 
 
 def test_cfg5_full_depth_batch32_properties_bf16():
