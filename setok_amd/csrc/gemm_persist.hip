@@ -864,6 +864,13 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "gemm_persist.hip is written for gfx950 (MI355X) only: the hand-scheduled waits, hazards and barriers in it are not valid elsewhere"
 #endif
+#ifndef PP_PHASES
+#define PP_PHASES 2         // phases (LOAD slot + MFMA slot) per K-tile: 4 = the quadrants, 16 MFMAs each (rounds 3-5); 2 = the row halves, 32 MFMAs each (round 6: same box,
+                            // alternating builds, cfg2 41.63 -> 40.77 ms, GEMM fraction 0.486 -> 0.4985, every class +1.5 ... +3 %; identical bits)
+#endif
+#ifndef PP_PH2_SPLIT
+#define PP_PH2_SPLIT 0      // PP_PHASES == 2 only. 1: LOAD A's second k-step A fragments are read BEHIND the slot's barrier, under the first 16 MFMAs (a shorter LOAD A slot) — A/B
+#endif
 #ifndef PP_RESYNC
 #define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
 #endif
@@ -1140,6 +1147,65 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
 #endif
             const char* T = smem + ((cnt + kt) & 1) * STAGE;
             const bool skipA = ahead != 0 && kt == 0;        // (uniform)
+#if PP_PHASES == 2
+            // ---- two phases of 32 MFMAs (round 6).  A slot of 16 MFMAs is 256 cycles of matrix-pipe time; the partner row's LOAD slot beside it — two LDS-DMA requests,
+            // up to eight fragment reads, their latency, the barrier — measures ~360, of which ~165 do not depend on how much the slot loads.  With the row
+            // halves as phases — (0,0)+(0,1), then (1,1)+(1,0) — a LOAD slot carries twice the requests and reads against 512 cycles of MFMAs: the fixed part is paid
+            // four times per K-tile instead of eight.  Same products into the same accumulators in the same order (k-step 0, then 1): identical bits.
+            // LOAD A: both A quarters of K-tile kt + 1 -> the other stage; every W fragment of this K-tile and the first row half's A fragments
+            if (!skipA) { issue_quarter(0, kt + 1); issue_quarter(1, kt + 1); }
+#if PP_PH2_SPLIT
+            rd_w(T, 0, W0); rd_w(T, 1, W1); rd_a(T, 0, 0, A0[0]);
+            lgk0();                                         // the last readers of this stage's W quarters retire BEFORE the barrier: LOAD B refills them
+            bar();
+            PPT_SLOT(0)
+            rd_a(T, 0, 1, A0[1]);                           // lands under the first 16 MFMAs (this stage's A quarters are refilled a K-tile later: no hazard)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma8(0, 0, A0[0], W0[0]);
+            mma8(0, 1, A0[0], W1[0]);
+            lgk0();
+            mma8(0, 0, A0[1], W0[1]);
+            mma8(0, 1, A0[1], W1[1]);
+            __builtin_amdgcn_s_setprio(0);
+#else
+            rd_w(T, 0, W0); rd_w(T, 1, W1); rd_a(T, 0, 0, A0[0]); rd_a(T, 0, 1, A0[1]);
+            lgk0();                                         // the last readers of this stage's W quarters retire BEFORE the barrier: LOAD B refills them
+            bar();
+            PPT_SLOT(0)
+            __builtin_amdgcn_s_setprio(1);
+            mma8(0, 0, A0[0], W0[0]);
+            mma8(0, 0, A0[1], W0[1]);
+            mma8(0, 1, A0[0], W1[0]);
+            mma8(0, 1, A0[1], W1[1]);
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            bar();
+            PPT_SLOT(1)
+            // LOAD B: both W quarters of K-tile kt + 2 -> this stage; the second row half's A fragments; the one wait of the K-tile (as in the four-phase form:
+            // row 1 at the end of its LOAD slot, row 0 at the end of its MFMA slot — the same barrier)
+            issue_quarter(2, kt + 2); issue_quarter(3, kt + 2);
+            rd_a(T, 1, 0, A1[0]); rd_a(T, 1, 1, A1[1]);    // (never behind the barrier: the other row's next LOAD A refills this stage's A quarters while this row multiplies)
+            lgk0();                                         // likewise this stage's A quarters (refilled by the next K-tile's LOAD A, or the epilogue)
+            const bool issued = kt + 2 < nk || has_next;    // the two W quarters of this K-tile exist
+            auto wait_next = [&]() {
+                if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (skipA && ahead == 1) wait_vm<4 + NSTORE + NAUX>();
+                else wait_vm<4>();
+            };
+            if (GRP == 1) wait_next();
+            bar();
+            PPT_SLOT(2)
+            __builtin_amdgcn_s_setprio(1);
+            mma8(1, 1, A1[0], W1[0]);
+            mma8(1, 1, A1[1], W1[1]);
+            mma8(1, 0, A1[0], W0[0]);
+            mma8(1, 0, A1[1], W0[1]);
+            __builtin_amdgcn_s_setprio(0);
+            if (GRP == 0) wait_next();
+            bar();
+            PPT_SLOT(3)
+#else
             // phase 0
             if (!skipA) issue_quarter(0, kt + 1);
             rd_w(T, 0, W0); rd_a(T, 0, 0, A0[0]);
@@ -1199,6 +1265,7 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             if (GRP == 0) wait_next();
             bar();
             PPT_SLOT(7)
+#endif
 #ifdef PP_TIMING
             {
                 const unsigned long long d = __builtin_amdgcn_s_memtime() - tkt0;
