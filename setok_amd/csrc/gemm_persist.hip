@@ -871,6 +871,9 @@ int launch_tail(hipStream_t s, const PArgs& g, int act, hipEvent_t e0, hipEvent_
 #ifndef PP_PH2_SPLIT
 #define PP_PH2_SPLIT 0      // PP_PHASES == 2 only. 1: LOAD A's second k-step A fragments are read BEHIND the slot's barrier, under the first 16 MFMAs (a shorter LOAD A slot) — A/B
 #endif
+#ifndef PP_PH2_READS_FIRST
+#define PP_PH2_READS_FIRST 0 // PP_PHASES == 2 only. 1: a LOAD slot's LDS-DMA requests go out BEHIND its fragment reads — A/B
+#endif
 #ifndef PP_RESYNC
 #define PP_RESYNC 1         // 1: the wave rows' one-slot offset is set up and taken back per tile (both epilogues at the same time); 0: once per launch (rounds 3-4)
 #endif
@@ -1086,7 +1089,10 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     unsigned long long t_kt0 = 0, t_kt1 = 0, t_kt2 = 0, t_kt3 = 0, t_ktr = 0, t_ktl = 0;     // K-tiles 0..3, the middle ones, the last one
     unsigned long long t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_pre = 0;                    // epilogue: before pass 0, passes 0..3
     unsigned long long t_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                      // the eight barrier-to-barrier slots of a tile's LAST K-tile
-#define PPT_SLOT(i) if (kt == nk - 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); t_s[i] += now_ - tsl; tsl = now_; }
+#ifndef PPT_KT
+#define PPT_KT (nk - 1)       // which K-tile of a tile the slot stamps are taken in (-DPPT_KT=6: a steady-state one)
+#endif
+#define PPT_SLOT(i) if (kt == PPT_KT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); t_s[i] += now_ - tsl; tsl = now_; }
 #else
 #define PPT_SLOT(i)
 #endif
@@ -1153,7 +1159,9 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             // halves as phases — (0,0)+(0,1), then (1,1)+(1,0) — a LOAD slot carries twice the requests and reads against 512 cycles of MFMAs: the fixed part is paid
             // four times per K-tile instead of eight.  Same products into the same accumulators in the same order (k-step 0, then 1): identical bits.
             // LOAD A: both A quarters of K-tile kt + 1 -> the other stage; every W fragment of this K-tile and the first row half's A fragments
+#if !PP_PH2_READS_FIRST
             if (!skipA) { issue_quarter(0, kt + 1); issue_quarter(1, kt + 1); }
+#endif
 #if PP_PH2_SPLIT
             rd_w(T, 0, W0); rd_w(T, 1, W1); rd_a(T, 0, 0, A0[0]);
             lgk0();                                         // the last readers of this stage's W quarters retire BEFORE the barrier: LOAD B refills them
@@ -1170,6 +1178,10 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             __builtin_amdgcn_s_setprio(0);
 #else
             rd_w(T, 0, W0); rd_w(T, 1, W1); rd_a(T, 0, 0, A0[0]); rd_a(T, 0, 1, A0[1]);
+#if PP_PH2_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+            if (!skipA) { issue_quarter(0, kt + 1); issue_quarter(1, kt + 1); }     // A/B: the requests BEHIND the fragment reads (their latency under the address unit's queue)
+#endif
             lgk0();                                         // the last readers of this stage's W quarters retire BEFORE the barrier: LOAD B refills them
             bar();
             PPT_SLOT(0)
@@ -1184,8 +1196,14 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             PPT_SLOT(1)
             // LOAD B: both W quarters of K-tile kt + 2 -> this stage; the second row half's A fragments; the one wait of the K-tile (as in the four-phase form:
             // row 1 at the end of its LOAD slot, row 0 at the end of its MFMA slot — the same barrier)
+#if !PP_PH2_READS_FIRST
             issue_quarter(2, kt + 2); issue_quarter(3, kt + 2);
+#endif
             rd_a(T, 1, 0, A1[0]); rd_a(T, 1, 1, A1[1]);    // (never behind the barrier: the other row's next LOAD A refills this stage's A quarters while this row multiplies)
+#if PP_PH2_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+            issue_quarter(2, kt + 2); issue_quarter(3, kt + 2);
+#endif
             lgk0();                                         // likewise this stage's A quarters (refilled by the next K-tile's LOAD A, or the epilogue)
             const bool issued = kt + 2 < nk || has_next;    // the two W quarters of this K-tile exist
             auto wait_next = [&]() {
@@ -1468,6 +1486,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(PArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef PP_TIMING           // the constant-rate (100 MHz) clock every workgroup of the chip reads the same: when did this workgroup start, and when did its first wave row end
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef PP_STAGGER_US       // A/B (round 6): every other workgroup of an XCD starts a residual launch late, so that the two halves' epilogues — each a burst of residual rows the
+                           // whole chip asks for at once — do not coincide
+    if (RESK && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(PP_STAGGER_US * 100)) __builtin_amdgcn_s_sleep(8);
+    }
 #endif
     if (wave < 4) gemm_pp_body<ACT, LNK, RESK, 0>(g, smem); else gemm_pp_body<ACT, LNK, RESK, 1>(g, smem);
 #ifdef PP_TIMING
