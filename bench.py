@@ -276,8 +276,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
-                    help="bf16 = the BASELINE metric's precision; f32 = the parity-exact mode (bit-exact cluster indices, 1e-4 features)")
+    ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16",
+                    help="bf16 = the BASELINE metric's precision; f16 = what the reference's inference loader casts the tower to (src/model/builder.py:135-136; "
+                         "libsetok_hip_f16.so, the same MFMA rate); f32 = the parity-exact mode (bit-exact cluster indices, 1e-4 features)")
     ap.add_argument("--select-layer", type=int, default=-1,
                     help="hidden_states index the tower returns: -1 (default) = what the reference's launch scripts pass and its training dataclass "
                          "defaults to (scripts/pretrain_mm_proj.sh:43, scripts/finetune.sh:67, src/train/training_utils.py:25: all 24 layers run); "
@@ -311,7 +312,7 @@ def main():
         sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: the launcher and the flag disagree")
     if args.launch_check:
         return launch_check(rank, world, local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -467,8 +468,8 @@ def main():
         if traffic is not None:
             traffic["file"] = f"{traffic['file']} (the builder's committed passes; live passes: {live_note})" 
     if rank == 0:
-        gname = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        gname = {"bf16": "gemm_bf16", "f16": "gemm_f16", "f32": "gemm_f32"}[args.dtype]
+        peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS                    # (fp16 and bf16 MFMA: the same dense peak)
         gemm = [p for p in prof if p["kernel"].split(":")[0] == gname]
         g_ms = sum(p["ms"] for p in gemm)
         g_fl = sum(p["flops"] for p in gemm)
@@ -496,7 +497,7 @@ def main():
                                     if trainer is not None else f"dp{world} (images sharded, no data-path collective)") + ("" if args.backend == "nccl" and not args.share_gpu else
                                                                                                    f" [VALIDATION RUN: backend {args.backend}, ranks share one GPU: not a scaling number]"),
                        "per_rank": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"]},
-            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<*> / gemm_persist_kernel<*> / gemm_tail_kernel<*> (every bf16 MFMA GEMM launch of the step)" if args.dtype == "bf16"
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<*> / gemm_persist_kernel<*> / gemm_tail_kernel<*> (every 16-bit MFMA GEMM launch of the step)" if args.dtype != "f32"
                          else "gemm_f32_kernel (exact-f32 MFMA GEMM, parity mode)",
                          "achieved": round(achieved, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -526,7 +527,7 @@ def main():
                                           "traffic": traffic["clustering"]["traffic_bytes_per_launch"] if traffic else None,
                                           "gram_tflops_over_the_call": round(gram_tf, 1),
                                           "ms_per_call": round(c_ms, 4), "share_of_step": round(c_ms * (len(clus) / max(probed_steps, 1)) / (dt / args.steps * 1e3), 4)}
-        if args.dtype == "bf16":
+        if args.dtype != "f32":
             res["roofline"]["mfma_only_random_operands_tflops"] = MFMA_ONLY_RANDOM_TFLOPS
             res["roofline"]["frac_of_mfma_only_random"] = round(achieved / MFMA_ONLY_RANDOM_TFLOPS, 4)
         if telemetry:
