@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Randomised parity sweep on the GPU (beyond the fixed shapes of tests/): python tools/fuzz_gpu.py [seconds] [seed].
+"""Randomised parity sweep on the GPU (beyond the fixed shapes of tests/): python tools/fuzz_gpu.py [seconds] [seed] [bf16|f16]
+(the third argument picks the 16-bit build under test: bf16 = libsetok_hip.so, f16 = libsetok_hip_f16.so — round 6).
 Linear (all kernels, activations, residual, folded LayerNorm), uniform / ragged / cross attention, the fused clustering against the multi-kernel
 form and against itself in other batch positions.  Prints the first failing case and exits non-zero."""
 import sys, os, time, random
@@ -12,6 +13,7 @@ DEV = "cuda"
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
+LOW = torch.float16 if len(sys.argv) > 3 and sys.argv[3] == "f16" else torch.bfloat16
 
 
 def rel(a, b):
@@ -26,14 +28,14 @@ def fuzz_linear():
     act = rng.randint(0, 2)
     use_res = rng.random() < 0.5
     g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
-    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
-    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+    a = torch.randn(M, K, generator=g).to(LOW).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(LOW).to(DEV)
     b = torch.randn(N, generator=g).to(DEV)
-    r = torch.randn(M, N, generator=g).bfloat16().to(DEV) if use_res else None
+    r = torch.randn(M, N, generator=g).to(LOW).to(DEV) if use_res else None
     got = ops.linear(a, w, b, r, act=act).float()
     ref = a.float() @ w.float().t() + b
     ref = ref * torch.sigmoid(1.702 * ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
-    ref = ref.bfloat16().float() + (r.float() if use_res else 0)
+    ref = ref.to(LOW).float() + (r.float() if use_res else 0)
     e = rel(got, ref)
     assert e < 2e-2, ("linear", M, N, K, act, use_res, e)
     # a slice of the rows through the small kernel: identical bits
@@ -50,8 +52,8 @@ def fuzz_linear_ln():
     K = 64 * rng.randint(1, 32)
     act = rng.randint(0, 2)
     g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
-    x = (torch.randn(M, K, generator=g) * (0.5 + 2 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g)).bfloat16().to(DEV)
-    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 2 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g)).to(LOW).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(LOW).to(DEV)
     gamma, beta, bias = (1 + 0.2 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
     st = ops.row_stats(x, 1e-5)
     got = ops.linear_ln(x, ops.ln_fold(w, gamma, beta, bias), st, act=act).float()
@@ -76,7 +78,7 @@ def fuzz_attention():
     T = rng.choice([1, 17, 32, 33, 64, 197, 256, 257, 300, 324, 577, rng.randint(1, 608)])
     n = rng.randint(1, 4)
     g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
-    qkv = torch.randn(n * T, 3 * H * Dh, generator=g).bfloat16().to(DEV)
+    qkv = torch.randn(n * T, 3 * H * Dh, generator=g).to(LOW).to(DEV)
     got = ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=T).float()
     q, k, v = qkv.float().reshape(n, T, 3, H, Dh).permute(2, 0, 3, 1, 4)
     ref = attn_ref(q, k, v, Dh ** -0.5).transpose(1, 2).reshape(n * T, H * Dh)
@@ -93,7 +95,7 @@ def fuzz_ragged_attention():
     for L in lens:
         offs.append(offs[-1] + L)
     g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
-    qkv = torch.randn(offs[-1], 3 * H * Dh, generator=g).bfloat16().to(DEV)
+    qkv = torch.randn(offs[-1], 3 * H * Dh, generator=g).to(LOW).to(DEV)
     so = torch.tensor(offs, dtype=torch.int32, device=DEV)
     got = ops.attention(qkv, H, Dh, Dh ** -0.5, seg_len=max(lens), seg_offsets=so, n_segs=len(lens)).float()
     for s0, s1 in zip(offs[:-1], offs[1:]):
@@ -113,8 +115,8 @@ def fuzz_cross_attention():
         offs.append(offs[-1] + L)
     C = H * Dh
     g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
-    q = torch.randn(len(lens) * q_len, C, generator=g).bfloat16().to(DEV)
-    kv = torch.randn(offs[-1], 2 * C, generator=g).bfloat16().to(DEV)
+    q = torch.randn(len(lens) * q_len, C, generator=g).to(LOW).to(DEV)
+    kv = torch.randn(offs[-1], 2 * C, generator=g).to(LOW).to(DEV)
     so = torch.tensor(offs, dtype=torch.int32, device=DEV)
     got = ops.cross_attention(q, kv[:, :C], kv[:, C:], H, Dh, Dh ** -0.5, q_len, so, len(lens), max(lens)).float()
     for i, (s0, s1) in enumerate(zip(offs[:-1], offs[1:])):
@@ -138,7 +140,7 @@ def fuzz_cluster():
     m = rng.randint(1, 16)
     cent = torch.randn(B, m, C, generator=g) * 2
     lab = torch.randint(0, m, (B, N), generator=g)
-    x = (torch.gather(cent, 1, lab[..., None].expand(B, N, C)) + rng.choice([0.05, 0.5, 1.0]) * torch.randn(B, N, C, generator=g)).bfloat16().to(DEV).reshape(B * N, C)
+    x = (torch.gather(cent, 1, lab[..., None].expand(B, N, C)) + rng.choice([0.05, 0.5, 1.0]) * torch.randn(B, N, C, generator=g)).to(LOW).to(DEV).reshape(B * N, C)
     noise = torch.rand(B, N, generator=g).to(DEV) if rng.random() < 0.5 else None
     mask = (torch.rand(B, N, generator=g) > 0.2).float().to(DEV) if rng.random() < 0.3 else None
     a = ops.cluster_dpc_knn(x, B, N, k, thr, mcn, noise, mask)
