@@ -8,8 +8,8 @@
 #include "../../include/setok_hip.h"
 
 // The 16-bit element type.  Every 16-bit kernel of the library is written against "a 16-bit float element, fp32 accumulation" under the name
-// `bf16` — the type of the BASELINE metric — and nothing in them depends on the exponent width except the three places marked SETOK_HALF
-// (the two-way / three-way exact splits that feed fp32 values to the matrix pipe).  The library is compiled TWICE from these sources:
+// `bf16` — the type of the BASELINE metric — and nothing in them depends on the exponent width except the places marked SETOK_HALF
+// (the two-way splits that feed fp32 start values to the matrix pipe; the round-2 GEMM's start at the bias, which is an exact three-way split in bf16 only).  The library is compiled TWICE from these sources:
 //   libsetok_hip.so       bf16 = __bf16,    v_mfma_f32_*_bf16, serves SETOK_F32 + SETOK_BF16
 //   libsetok_hip_f16.so   bf16 = _Float16,  v_mfma_f32_*_f16 (the same rate), serves SETOK_F32 + SETOK_F16   (-DSETOK_HALF; round 6)
 // — the reference's inference loader and its non-bf16 launches run the tower in torch.float16 (src/model/builder.py:43,135-136,

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     // holds the bias split into three bf16 parts (hi + mid + lo = the fp32 value exactly) against a fragment of ones: acc = 0 + hi + mid + lo
     // is exact, so the arithmetic (bias first, then the products in ascending k) is unchanged bit for bit.
     float nb[NT];
+#ifdef SETOK_HALF
+    f32x4 nbq[NT];
+#endif
     // LNK: a lane fetches ONE column fragment (16 bytes: column g4 * 16 + l15 of the wave's 64) and the compact form (8 bytes) of TWO row
     // fragments (rows (2 g4 + i) * 16 + l15 of the wave's 128) — 8 registers instead of 48 for the tile's 12 fragments; at the tile's start the
     // lanes that feed the MFMA's k-slots 0-7 (lanes 0-15) collect them from the other 16-lane groups with ds_bpermute.
@@ -195,8 +198,17 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
     auto load_bias = [&](int n0_, int m0_) {
         if constexpr (!F32B && !LNK) {
             const float* bp = g.bias ? g.bias + min(n0_ + wn * 64, g.N - 64) : g.zero_bias;
+#ifdef SETOK_HALF
+            // fp16 build: the accumulators start at the fp32 bias DIRECTLY (a lane's quad = columns j * 16 + 4 g4 .. + 3, as in the ping-pong and small-tile
+            // kernels).  The matrix-pipe start of the bf16 build needs an EXACT split of an fp32 value into 16-bit parts: bf16 has fp32's exponent range, fp16
+            // does not — the third part of a bias of order 1 is 2^-22, a subnormal half with two bits left — and a start value one fp32 ulp off flipped the
+            // fp16 rounding of 8e-5 of this kernel's outputs against the other kernels' (tools/fuzz_gpu.py ... f16, seed 7).
+#pragma unroll
+            for (int j = 0; j < NT; ++j) nbq[j] = *reinterpret_cast<const f32x4*>(bp + (g.bias ? j * 16 + 4 * g4 : 0));
+#else
 #pragma unroll
             for (int j = 0; j < NT; ++j) nb[j] = bp[j * 16 + l15];
+#endif
         }
     };
     // They are fetched in the MIDDLE of the previous tile's epilogue (after its second pass), so that their L2 round trip (1-2 us under
@@ -316,6 +328,20 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                 for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfr[j], rfr, z, 0, 0, 0);
             }
         } else {   // ---- accumulators start at the bias (fp32, added before the single bf16 rounding) -------------------------------------------
+#ifdef SETOK_HALF
+            if constexpr (F32B) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[t][j] = z; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[t][j] = nbq[j];
+            }
+        }
+#else
             bf16x8 ones;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
@@ -325,17 +351,6 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bw[e] = (bf16)0.0f;
                 if constexpr (!F32B) {
-#ifdef SETOK_HALF
-                    // fp16 build: three-way split by rounding — 33 bits of significand, exact for every bias whose parts stay normal (|b| < 65504; a part
-                    // below 2^-24 is dropped: an absolute error the fp16 output cannot hold); only the k-group-0 lanes carry it
-                    const float b = nb[j];
-                    const bf16 h1 = (bf16)b;
-                    const bool fin = __builtin_isfinite((float)h1);
-                    const float r1 = fin ? b - (float)h1 : 0.f;
-                    const bf16 h2 = (bf16)r1;
-                    const float r2 = r1 - (float)h2;
-                    if (g4 == 0) { bw[0] = h1; bw[1] = h2; bw[2] = (bf16)r2; }
-#else
                     // three-way exact split by truncation (top 16 bits of the fp32 pattern each time); only the k-group-0 lanes carry it
                     const float b = nb[j];
                     const float hi1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffff0000u);
@@ -348,7 +363,6 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                         bw[1] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r1) >> 16)) : (bf16)0.0f;
                         bw[2] = fin ? __builtin_bit_cast(bf16, (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16)) : (bf16)0.0f;
                     }
-#endif
                 }
                 f32x4 z;
 #pragma unroll
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs g) {
                 for (int t = 0; t < MT; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, ones, z, 0, 0, 0);
             }
         }
+#endif
         multiply(no{}, false, 0);                                                 // K-tile 1 was requested at the previous tile boundary
         {
             const unsigned long long w0 = g.tim ? __builtin_amdgcn_s_memtime() : 0;

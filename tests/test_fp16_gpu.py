@@ -69,10 +69,13 @@ def test_linear_fp16(M, N, K, act, res):
         assert _rel(got32, ref) < 2e-5                      # fp16 products are exact in fp32; only the accumulation order differs
 
 
-@pytest.mark.parametrize("N,K", [(1024, 1024), (4096, 1024), (1024, 4096)])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (4096, 1024), (1024, 4096), (2368, 448)])
 @pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (2, True), (0, True)])
 def test_linear_fp16_rows_do_not_depend_on_the_kernel(act, use_res, N, K):
-    """Batch invariance holds in the fp16 build as in the bf16 one: the same rows through the persistent kernel and every small-tile shape give the same bits."""
+    """Batch invariance holds in the fp16 build as in the bf16 one: the same rows through the persistent kernel and every small-tile shape give the same bits.
+    (N = 2368 is not a multiple of 256: the round-2 persistent kernel.  Its accumulators started at the bias through the matrix pipe from an "exact" three-way
+    16-bit split — exact in bf16, which has fp32's exponent range, not in fp16, where the third part of a bias of order 1 is a subnormal with two bits left: 8e-5 of
+    its outputs were one fp16 ulp off the other kernels'.  Found by tools/fuzz_gpu.py ... f16, seed 7; the fp16 build starts at the fp32 bias directly.)"""
     M = 25088
     a, w = _rand(M, K, seed=11).to(DEV, H), _rand(N, K, seed=12, scale=K ** -0.5).to(DEV, H)
     b = _rand(N, seed=13).to(DEV)
