@@ -238,8 +238,10 @@ def test_336_input_576_patches(dt, tol):
             parity.close(toks[i], ref[i].tokens, TOL, "toks[i], ref[i].tokens")
 
 
-def test_full_size_batch_invariance_and_properties():
-    """BASELINE cfg2 at full size (B = 256, ViT-L/14-224, bf16, dyn-k): size-independent properties.
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_full_size_batch_invariance_and_properties(dt):
+    """(dt = float16, round 6: the same properties in the fp16 build, B = 256 — every kernel class of libsetok_hip_f16.so at the headline's shapes.)
+    BASELINE cfg2 at full size (B = 256, ViT-L/14-224, bf16, dyn-k): size-independent properties.
     Images are independent units and every kernel's arithmetic per output row is independent of the
     other rows, so an image's result must be BIT-IDENTICAL whether it is encoded in the batch of 256 or in a batch of 3;
     plus determinism and the structural invariants of the clustering."""
@@ -247,9 +249,9 @@ def test_full_size_batch_invariance_and_properties():
     tok = SetokTokenizer(vision_tower=vars(O.VitConfig()), hidden_dim=1024, token_feat_dim=4096, min_cluster_num=64,
                          threshold=0.125, nheads=2, dim_feedforward=4096)
     init_synthetic_(tok, 0, 1)
-    tok = tok.to(device=DEV, dtype=torch.bfloat16).eval()
+    tok = tok.to(device=DEV, dtype=dt).eval()
     g = torch.Generator().manual_seed(11)
-    images = torch.randn(256, 3, 224, 224, generator=g).to(DEV, torch.bfloat16)
+    images = torch.randn(256, 3, 224, 224, generator=g).to(DEV, dt)
     toks, idx, score = tok(images)
     toks2, idx2, score2 = tok(images)
     assert torch.equal(toks.packed, toks2.packed) and torch.equal(idx, idx2) and torch.equal(score, score2)      # deterministic

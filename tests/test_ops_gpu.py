@@ -785,3 +785,43 @@ def test_cluster_strips_on_a_cu_masked_stream():
     finally:
         hip.hipStreamDestroy(st)
     assert all(torch.equal(u, v) for u, v in zip(full, small))
+
+
+_MERGE_REM_CASES = [(act, res, ln) for act in (0, 1, 2) for res in (False, True) for ln in (False, True) if not (res and ln)]
+
+
+def _merge_rem_outputs():
+    """Every activation x residual x folded-LayerNorm combination of the ping-pong GEMM at M = 257 tile rows + 3 rows (the ViT's shape class: whole 256-row
+    tiles + a remainder), N = 1024 (32 x 32 remainder tiles) and N = 3072 (64 x 64): outputs as a list of CPU tensors."""
+    outs = []
+    for N, K in ((1024, 1024), (3072, 768)):
+        M = 256 * 24 + 259
+        a = (_rand(M, K, seed=21) * 1.3 + 0.2).bfloat16().to(DEV)
+        w = _rand(N, K, seed=22, scale=K ** -0.5).bfloat16().to(DEV)
+        b = _rand(N, seed=23).to(DEV)
+        r = _rand(M, N, seed=24).bfloat16().to(DEV)
+        gamma, beta = (1.0 + 0.1 * _rand(K, seed=25)).to(DEV), (0.1 * _rand(K, seed=26)).to(DEV)
+        for act, res, ln in _MERGE_REM_CASES:
+            if ln:
+                outs.append(ops.linear_ln(a, ops.ln_fold(w, gamma, beta, b), ops.row_stats(a, 1e-5), act=act).cpu())
+            else:
+                outs.append(ops.linear(a, w, b, r if res else None, act=act).cpu())
+    return outs
+
+
+def test_remainder_rows_inside_the_launch_equal_the_separate_launch(tmp_path):
+    """since round 5 a ping-pong launch finishes the rows behind its last whole 256-row tile itself (PP_MERGE_REM; the first wave row runs the
+    small-tile kernel's tile function while the second has ended — correct only because s_barrier counts the surviving waves).  SETOK_GEMM_MERGE_REM=0 sends
+    them to a launch of the small-tile kernel as rounds 3-4 did.  The switch is read once per process, so the other arm runs in a child process: identical
+    bits for every activation x residual x folded-LayerNorm combination, at both remainder tile shapes."""
+    import subprocess, sys
+    here = _merge_rem_outputs()
+    path = str(tmp_path / "separate.pt")
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]; import test_ops_gpu as t; torch.set_grad_enabled(False); torch.save(t._merge_rem_outputs(), %r)"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path))
+    env = dict(os.environ, SETOK_GEMM_MERGE_REM="0", PYTHONPATH=os.pathsep.join(sys.path))
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+    there = torch.load(path)
+    assert len(here) == len(there) == 2 * len(_MERGE_REM_CASES)
+    for i, (x, y) in enumerate(zip(here, there)):
+        assert torch.equal(x, y), (i, _MERGE_REM_CASES[i % len(_MERGE_REM_CASES)])
