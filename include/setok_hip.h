@@ -388,6 +388,15 @@ int setok_rope_gqa(void* stream, int dtype, void* qkv, const int64_t* position_i
 
 /* LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) on a fused (rows, 2*F) buffer [gate | up] -> (rows, F); act_fn = SiLU. */
 int setok_swiglu(void* stream, int dtype, const void* gate_up, void* out, int64_t rows, int F);
+/* ... on a buffer of INTERLEAVED pairs: gate_up_pairs (rows, 2 F) with (gate_j, up_j) in columns 2 j, 2 j + 1 — the output layout of a Linear whose weight
+ * rows are interleaved the same way (setok_linear_swiglu's).  Same arithmetic, same bits as setok_swiglu on the de-interleaved buffer. */
+int setok_swiglu_pairs(void* stream, int dtype, const void* gate_up_pairs, void* out, int64_t rows, int F);
+/* out (M, F) = act_fn(A Wg^T) * (A Wu^T) in ONE launch: the gate|up Linear of LlamaMLP (HF modeling_llama.py LlamaMLP.forward, reached from
+ * /root/reference/src/model/language_model/setokim_llama.py:130-143) with SwiGLU in the GEMM's epilogue — the (M, 2 F) intermediate is never written.
+ * W_pairs (2 F, K): row 2 j = gate_proj.weight[j], row 2 j + 1 = up_proj.weight[j].  torch's 16-bit rounding points are kept (gate and up rounded to the
+ * element type, the activation rounded, the product rounded), so the result equals setok_linear(W_pairs) followed by setok_swiglu_pairs bit for bit.
+ * 16-bit element types; M % 256 == 0, (2 F) % 256 == 0, K % 64 == 0, K >= 128, else SETOK_EUNSUPPORTED (send those rows through the unfused pair). */
+int setok_linear_swiglu(void* stream, int dtype, const void* A, int64_t lda, const void* W_pairs, void* out, int64_t ldo, int M, int F, int K);
 
 /* Causal self-attention of LlamaAttention (eager_attention_forward: softmax(q k^T * scale + mask) v, fp32 softmax) over B
  * sequences of T rows of a fused [q | k | v] buffer (num_key_value_heads == num_attention_heads).  Query i of a sequence sees key

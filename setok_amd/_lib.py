@@ -87,6 +87,8 @@ SIGNATURES = {
     "setok_rope": [_vp, _i, _vp, _vp, _i, _i, _i, _f],
     "setok_rope_gqa": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f],
     "setok_swiglu": [_vp, _i, _vp, _vp, _i64, _i],
+    "setok_swiglu_pairs": [_vp, _i, _vp, _vp, _i64, _i],
+    "setok_linear_swiglu": [_vp, _i, _vp, _i64, _vp, _vp, _i64, _i, _i, _i],
     "setok_attention_causal": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f],
     "setok_attention_causal_gqa": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f],
     "setok_lm_loss": [_vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp],

@@ -233,6 +233,19 @@ __device__ inline bf16x8 ln_row_frag(float mean, float rstd) {          // the a
     return f;
 }
 
+// SwiGLU on one (gate, up) pair of fp32 accumulator values with torch's 16-bit rounding points (HF LlamaMLP in the element type: gate_proj / up_proj outputs rounded,
+// act_fn's result rounded, the product rounded): the ONE definition behind the fused GEMM epilogue (gemm_persist.hip) and setok_swiglu / setok_swiglu_pairs (llama.hip), so a
+// row's bits do not depend on which of them produced it.  16-bit types: v_exp_f32 / v_rcp_f32 (1 ulp-class, far below the type's rounding); fp32 keeps expf and the division.
+template <typename T>
+__device__ inline T swiglu16(float gate, float up) {
+    const float g = (float)(T)gate, u = (float)(T)up;
+    float s;
+    if constexpr (sizeof(T) == 4) s = g / (1.0f + expf(-g));
+    else s = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * g));
+    return (T)((float)(T)s * u);
+}
+constexpr int SETOK_ACT_SWIGLU_PAIRS = 3;      // internal (not an `act` of setok_linear): the ping-pong GEMM's SwiGLU epilogue, reached through setok_linear_swiglu only
+
 __device__ inline float act_apply(float v, int act) {
     if (act == SETOK_ACT_QUICK_GELU) return v / (1.0f + expf(-1.702f * v));
     if (act == SETOK_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));

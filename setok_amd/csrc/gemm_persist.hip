@@ -905,7 +905,9 @@ template <int ACT, bool LNK, bool RESK, int GRP>
 __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
     static_assert(!(LNK && RESK), "the folded LayerNorm feeds q|k|v / fc1: no residual");
     constexpr int QT = 16 * 1024;
-    constexpr int NSTORE = 16;
+    constexpr bool SWG = ACT == SETOK_ACT_SWIGLU_PAIRS;       // round 6: act_fn(gate) * up in the epilogue; the tile's 256 columns are 128 (gate, up) pairs -> 128 output columns
+    static_assert(!(SWG && (LNK || RESK)), "the SwiGLU epilogue has no folded LayerNorm and no residual");
+    constexpr int NSTORE = SWG ? 8 : 16;                    // 16-byte stores per lane and tile
     // entries of the vector-memory queue a tile's epilogue puts BEHIND the A quarters of the next tile's K-tile 1: the next tile's start values
     // (bias / LN fragments: 4 / 5 ordinary loads) and, with a residual, the residual rows of passes 1-3 (12 loads); + the 16 stores
     constexpr int NAUX = (LNK ? (PP_LN_PACK ? 6 : 14) : 4) + (RESK ? 12 : 0);
@@ -1327,11 +1329,12 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
             asm volatile("" : "+v"(lane_e));
             const int slot = lane_e & 7, lrow = lane_e >> 3;
             char* stg = smem + 2 * STAGE + wave * 4096;
-            const int64_t wave_elem = (int64_t)(m0 + GRP * 128) * g.ldc + (n0 + wn * 64);
+            // (SwiGLU: the wave's 64 columns are 32 (gate, up) pairs = 32 output columns; an output row piece is 64 bytes = 4 slots, a pass's 32 rows two store rounds of 16 rows)
+            const int64_t wave_elem = (int64_t)(m0 + GRP * 128) * g.ldc + (SWG ? n0 / 2 + wn * 32 : n0 + wn * 64);
             char* c_wave = reinterpret_cast<char*>(g.C + wave_elem);
             const char* r_wave = reinterpret_cast<const char*>(g.res + (RESK ? wave_elem : 0));
-            const unsigned lane_off = (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
-            const unsigned row8 = (unsigned)g.ldc * 16u;
+            const unsigned lane_off = SWG ? (unsigned)((lane_e >> 2) * (int)g.ldc + (lane_e & 3) * 8) * 2u : (unsigned)(lrow * (int)g.ldc + slot * 8) * 2u;
+            const unsigned row8 = (unsigned)g.ldc * (SWG ? 32u : 16u);           // bytes between consecutive store rounds (8 rows; SwiGLU: 16 rows)
 #if PP_NT_STORE
             const unsigned long long c_wave_s = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)c_wave) |
                                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)c_wave >> 32)) << 32);
@@ -1376,6 +1379,16 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                         typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
                         bf16x4 v;
                         const f32x4 xq = acc[2 * h + tt][j];
+                        if constexpr (SWG) {
+                            // the quad is (gate, up, gate, up) of output columns j * 8 + 2 g4, + 1: two outputs, 4 bytes, into a 64-byte staging row whose 16-byte slot is
+                            // XOR-ed with (row >> 1) & 3 (16 rows 64 bytes apart would meet in 4 banks).  swiglu16: torch's rounding points (gate and up to the element
+                            // type, the activation, the product) — the bits of setok_swiglu_pairs on the unfused GEMM's output
+                            bf16x2 o2;
+                            o2[0] = swiglu16<bf16>(xq[0], xq[1]); o2[1] = swiglu16<bf16>(xq[2], xq[3]);
+                            const int srow = tt * 16 + l15;
+                            *reinterpret_cast<bf16x2*>(stg + srow * 64 + ((j ^ ((srow >> 1) & 3)) << 4) + 4 * g4) = o2;
+                            continue;
+                        }
                         if constexpr (ACT == SETOK_ACT_GELU_ERF) {           // (element by element as in the other kernels: on pairs the compiler contracts
                             f32x4 xs = xq;                                   //  the polynomial differently and the last bit moves)
 #ifndef PP_ABL_NOSCALE
@@ -1404,10 +1417,18 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 bf16x8 ov[4];
+                if constexpr (SWG) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 16 + (lane_e >> 2);
+                        ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 64 + (((lane_e & 3) ^ ((row >> 1) & 3)) << 4));
+                    }
+                } else {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + lrow;
                     ov[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((slot ^ (row & 7)) << 4));
+                }
                 }
                 if constexpr (RESK) {
 #pragma unroll
@@ -1425,8 +1446,8 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                 // a tile of this workgroup): a conditional load would make the values loop-carried and keep their registers live across the K loop.
                 if (h == PP_START_PASS) load_start(nn0, nm0);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int grow = m0 + GRP * 128 + h * 32 + it * 8 + lrow;
+                for (int it = 0; it < (SWG ? 2 : 4); ++it) {
+                    const int grow = m0 + GRP * 128 + h * 32 + (SWG ? it * 16 + (lane_e >> 2) : it * 8 + lrow);
                     if (interior || grow < Mrt) {
 #if PP_NT_STORE
                         if constexpr (PP_NT_STORE == 1 || (PP_NT_STORE == 2 && !RESK) || (PP_NT_STORE == 3 && RESK)) {
@@ -1437,10 +1458,10 @@ __device__ __forceinline__ void gemm_pp_body(const PArgs& g, char* smem) {
                             if constexpr (RESK)
                                 asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C_RES "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
                             else
-                                asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * 4 + it) * row8) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, %2" PP_POL_C "\n\ts_nop 1" :: "v"(lane_off), "v"(ov[it]), "s"(c_wave_s + (unsigned long long)(h * (SWG ? 2 : 4) + it) * row8) : "memory");
                         } else
 #endif
-                        *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * 4 + it) * row8 + lane_off) = ov[it];
+                        *reinterpret_cast<bf16x8*>(c_wave + (size_t)(h * (SWG ? 2 : 4) + it) * row8 + lane_off) = ov[it];
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the staging rows are rewritten by the next pass)
@@ -1551,7 +1572,8 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
         static SetokDeviceOnce once_pp;
         if (!once_pp.run([] {
                 bool ok = true;
-                const void* fns[] = {(const void*)gemm_pp_kernel<0, false>, (const void*)gemm_pp_kernel<1, false>, (const void*)gemm_pp_kernel<2, false>,
+                const void* fns[] = {(const void*)gemm_pp_kernel<SETOK_ACT_SWIGLU_PAIRS, false>,
+                                     (const void*)gemm_pp_kernel<0, false>, (const void*)gemm_pp_kernel<1, false>, (const void*)gemm_pp_kernel<2, false>,
                                      (const void*)gemm_pp_kernel<0, true>, (const void*)gemm_pp_kernel<1, true>, (const void*)gemm_pp_kernel<2, true>,
                                      (const void*)gemm_pp_kernel<0, false, true>, (const void*)gemm_pp_kernel<1, false, true>, (const void*)gemm_pp_kernel<2, false, true>};
                 for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAIN_LDS) == hipSuccess;
@@ -1565,7 +1587,8 @@ int launch_main(hipStream_t s, const PArgs& g, int act, int n_cu, hipEvent_t e0,
             if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
             else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
             else setok_launch(gemm_pp_kernel<2, false, true>, gr, bl, MAIN_LDS, s, e0, e1, g);
-        } else if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        } else if (act == SETOK_ACT_SWIGLU_PAIRS) setok_launch(gemm_pp_kernel<SETOK_ACT_SWIGLU_PAIRS, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
+        else if (act == SETOK_ACT_NONE) setok_launch(gemm_pp_kernel<0, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
         else if (act == SETOK_ACT_QUICK_GELU) setok_launch(gemm_pp_kernel<1, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
         else setok_launch(gemm_pp_kernel<2, false>, gr, bl, MAIN_LDS, s, e0, e1, g);
         SETOK_CHECK_LAUNCH("setok_linear(ping-pong)");
@@ -1713,6 +1736,16 @@ int setok_gemm_persist_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf1
 
 // Called by setok_linear for SMALL bf16 -> bf16 problems (a handful of images: too few 128 x 128 tiles to fill 256 CUs): the deep-pipelined
 // 64 x 64 kernel over the whole problem.
+// act_fn(gate) * up in the epilogue of the gate|up GEMM (setok_linear_swiglu, llama.hip): W holds (gate_j, up_j) as rows 2 j, 2 j + 1; C is (M, N / 2).  Whole
+// 256-row tiles of the ping-pong kernel only (the caller sends the rows behind them through setok_linear + setok_swiglu_pairs: the same bits).
+int setok_gemm_swiglu_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, bf16* C, int64_t ldc, int M, int N, int K) {
+    if (M % TM != 0 || N % 256 != 0 || K % TK != 0 || K < 128 || !pp_enabled() || PP_TIMING_ON) return SETOK_EUNSUPPORTED;
+    const float* zb = zero_bias();
+    if (!zb) return setok_fail(SETOK_ELAUNCH, "setok_linear_swiglu: cannot resolve the zero-bias symbol");
+    PArgs g{A, W, nullptr, nullptr, C, lda, ldc, M, N, K, M / TM, N / 256, 0, nullptr, zb, nullptr, 0, 0, 0, 1, nullptr, nullptr, nullptr};
+    return launch_main(s, g, SETOK_ACT_SWIGLU_PAIRS, cu_count(), setok_prof_start_event(), setok_prof_stop_event());
+}
+
 int setok_gemm_small_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, const float* bias, const bf16* res,
                           bf16* C, int64_t ldc, int M, int N, int K, int act, const float* ln_stats, const float* ln_colsum, const int32_t* m_dev) {
     const TailShape sh = tail_shape_for(M, N, cu_count(), !ln_stats && !m_dev);

@@ -131,8 +131,24 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T
         float g[V], u[V];
         ld_vec<T>(gu + r * 2 * F + c, g); ld_vec<T>(gu + r * 2 * F + F + c, u);
 #pragma unroll
-        for (int e = 0; e < V; ++e) g[e] = rnd<T>(g[e] / (1.0f + expf(-g[e]))) * u[e];
+        for (int e = 0; e < V; ++e) g[e] = (float)swiglu16<T>(g[e], u[e]);
         st_vec<T>(out + r * F + c, g);
+    }
+}
+
+// ... on INTERLEAVED (gate_j, up_j) pairs: the layout the fused gate|up GEMM takes its weights in (setok_linear_swiglu), for the rows it leaves to the unfused pair
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_pairs_kernel(const T* __restrict__ gu, T* __restrict__ out, int64_t rows, int F) {
+    constexpr int V = Elem<T>::VEC;                                   // V outputs per thread from 2 V inputs: two 16-byte loads, one 16-byte store
+    const int chunks = F / V;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks; const int c = (int)(i % chunks) * V;
+        float a[V], b[V], o[V];
+        ld_vec<T>(gu + r * 2 * F + 2 * c, a); ld_vec<T>(gu + r * 2 * F + 2 * c + V, b);
+#pragma unroll
+        for (int e = 0; e < V / 2; ++e) { o[e] = (float)swiglu16<T>(a[2 * e], a[2 * e + 1]); o[V / 2 + e] = (float)swiglu16<T>(b[2 * e], b[2 * e + 1]); }
+        st_vec<T>(out + r * F + c, o);
     }
 }
 
@@ -452,6 +468,34 @@ extern "C" int setok_swiglu(void* stream, int dtype, const void* gate_up, void* 
                 (swiglu_kernel<float><<<grid, 256, 0, s>>>((const float*)gate_up, (float*)out, rows, F)));
     SETOK_CHECK_LAUNCH("setok_swiglu");
     return SETOK_OK;
+}
+
+extern "C" int setok_swiglu_pairs(void* stream, int dtype, const void* gate_up_pairs, void* out, int64_t rows, int F) {
+    SETOK_CHECK_ARG(gate_up_pairs && out && rows >= 0 && F > 0 && F % 8 == 0, "setok_swiglu_pairs: bad operand (F must be a multiple of 8)");
+    if (rows == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = rows * (F / (dtype == SETOK_BF16 ? 8 : 4));
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    LL_DISPATCH("setok_swiglu_pairs", (swiglu_pairs_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)gate_up_pairs, (bf16*)out, rows, F)),
+                (swiglu_pairs_kernel<float><<<grid, 256, 0, s>>>((const float*)gate_up_pairs, (float*)out, rows, F)));
+    SETOK_CHECK_LAUNCH("setok_swiglu_pairs");
+    return SETOK_OK;
+}
+
+int setok_gemm_swiglu_bf16(hipStream_t s, const bf16* A, int64_t lda, const bf16* W, bf16* C, int64_t ldc, int M, int N, int K);   // gemm_persist.hip
+
+extern "C" int setok_linear_swiglu(void* stream, int dtype, const void* A, int64_t lda, const void* W_pairs, void* out, int64_t ldo, int M, int F, int K) {
+    SETOK_CHECK_ARG(A && W_pairs && out, "setok_linear_swiglu: null operand");
+    SETOK_CHECK_ARG(M >= 0 && F > 0 && K > 0 && lda >= K && ldo >= F && lda % 8 == 0 && ldo % 8 == 0, "setok_linear_swiglu: bad shape M=%d F=%d K=%d", M, F, K);
+    if (dtype != SETOK_BF16) return setok_fail(SETOK_EUNSUPPORTED, "setok_linear_swiglu: 16-bit element types only (the caller runs setok_linear + setok_swiglu_pairs in fp32)");
+    if (M == 0) return SETOK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    SetokProfScope prof(s, SETOK_PROF_GEMM_BF16, 0, 2.0 * M * (2.0 * F) * K, ((double)M * K + 2.0 * F * K) * 2.0 + (double)M * F * 2.0, true);
+    const int rc = setok_gemm_swiglu_bf16(s, (const bf16*)A, lda, (const bf16*)W_pairs, (bf16*)out, ldo, M, 2 * F, K);
+    if (rc == SETOK_EUNSUPPORTED)
+        return setok_fail(SETOK_EUNSUPPORTED, "setok_linear_swiglu: needs M %% 256 == 0, (2 F) %% 256 == 0, K %% 64 == 0, K >= 128 (M=%d F=%d K=%d): "
+                                              "send other rows through setok_linear + setok_swiglu_pairs (identical bits)", M, F, K);
+    return rc;
 }
 
 extern "C" int setok_attention_causal_gqa(void* stream, int dtype, const void* qkv, const uint8_t* key_mask, void* out, int B, int T, int H, int Hkv,

@@ -88,7 +88,7 @@ class LlamaModel(PackCacheMixin, nn.Module):
             layers.append(dict(n1=f32(l.input_layernorm.weight), n2=f32(l.post_attention_layernorm.weight),
                                wqkv=torch.cat([a.q_proj.weight.detach(), a.k_proj.weight.detach(), a.v_proj.weight.detach()], 0).contiguous(),
                                wo=a.o_proj.weight.detach().contiguous(),
-                               wgu=torch.cat([m.gate_proj.weight.detach(), m.up_proj.weight.detach()], 0).contiguous(),
+                               wgu=ops.interleave_gate_up(m.gate_proj.weight.detach(), m.up_proj.weight.detach()),      # (gate_j, up_j) row pairs: linear_swiglu
                                wd=m.down_proj.weight.detach().contiguous()))
         self._packed = dict(key=key, layers=layers, norm=f32(self.norm.weight))
         return self._packed
@@ -119,8 +119,7 @@ class LlamaModel(PackCacheMixin, nn.Module):
             o = ops.attention_causal(qkv, km, B, T, H, dh, dh ** -0.5, Hkv)
             ops.linear(o, L["wo"], residual=x, out=x)
             y = ops.rmsnorm(x, L["n2"], self.eps, out=y)
-            gu = ops.linear(y, L["wgu"])
-            g = ops.swiglu(gu)
+            g = ops.linear_swiglu(y, L["wgu"])                           # gate|up Linear with SwiGLU in its epilogue (16-bit modes; the unfused pair otherwise: same bits)
             ops.linear(g, L["wd"], residual=x, out=x)
         return ops.rmsnorm(x, pk["norm"], self.eps, out=y).reshape(B, T, D)
 

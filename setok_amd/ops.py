@@ -4,6 +4,8 @@ PyTorch is plumbing here (device memory + streams); every operator below is one 
 libsetok_hip.so on torch's current HIP stream."""
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional, Tuple
 
@@ -522,6 +524,38 @@ def swiglu(gate_up: Tensor) -> Tensor:
     rows, F2 = gate_up.shape
     out = torch.empty((rows, F2 // 2), dtype=gate_up.dtype, device=gate_up.device)
     _lib.call("setok_swiglu", _stream(), _code(gate_up.dtype), _p(gate_up), _p(out), rows, F2 // 2)
+    return out
+
+
+def swiglu_pairs(gate_up_pairs: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """act_fn(gate) * up on INTERLEAVED (gate_j, up_j) columns — the output of `linear` with pair-interleaved weight rows (interleave_gate_up)."""
+    rows, F2 = gate_up_pairs.shape
+    if out is None:
+        out = torch.empty((rows, F2 // 2), dtype=gate_up_pairs.dtype, device=gate_up_pairs.device)
+    _lib.call("setok_swiglu_pairs", _stream(), _code(gate_up_pairs.dtype), _p(gate_up_pairs), _p(out), rows, F2 // 2)
+    return out
+
+
+def interleave_gate_up(gate_w: Tensor, up_w: Tensor) -> Tensor:
+    """(F, K), (F, K) -> (2 F, K) with row 2 j = gate_w[j], row 2 j + 1 = up_w[j]: the weight layout of linear_swiglu."""
+    assert gate_w.shape == up_w.shape
+    return torch.stack([gate_w, up_w], dim=1).reshape(2 * gate_w.shape[0], gate_w.shape[1]).contiguous()
+
+
+def linear_swiglu(a: Tensor, w_pairs: Tensor) -> Tensor:
+    """act_fn(a @ Wg.T) * (a @ Wu.T) for pair-interleaved weights (interleave_gate_up): LlamaMLP's gate|up Linear + SwiGLU.  In the 16-bit modes the whole 256-row
+    tiles go through ONE launch (SwiGLU in the GEMM's epilogue: the (M, 2 F) intermediate is never written); the rows behind them — and everything when the
+    problem is too small for the persistent kernel, or in fp32 — through `linear` + `swiglu_pairs`.  The two forms give the same bits (the epilogue keeps torch's
+    rounding points), so a row's result does not depend on which of them it took."""
+    M, K = a.shape
+    F2 = w_pairs.shape[0]
+    out = torch.empty((M, F2 // 2), dtype=a.dtype, device=a.device)
+    main = 0
+    if os.environ.get("SETOK_SWIGLU_FUSED", "1") != "0" and a.dtype in LOW and F2 % 256 == 0 and K % 64 == 0 and K >= 128 and (M // 256) * (F2 // 256) >= 90:
+        main = M // 256 * 256
+        _lib.call("setok_linear_swiglu", _stream(), _code(a.dtype), _p(a), K, _p(w_pairs), _p(out), F2 // 2, main, F2 // 2, K)
+    if main < M:
+        swiglu_pairs(linear(a[main:], w_pairs), out=out[main:])
     return out
 
 

@@ -62,6 +62,41 @@ def test_swiglu(dt, tol):
     assert _rel(ops.swiglu(gu.to(DEV)), ref.double()) < tol
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_swiglu_pairs_equals_swiglu_on_the_deinterleaved_buffer(dt):
+    """setok_swiglu_pairs reads (gate_j, up_j) column pairs — the output layout of a Linear with pair-interleaved weight rows; same arithmetic, same bits as
+    setok_swiglu on [gate | up]."""
+    Fd = 352
+    gu = (_rand(77, 2 * Fd, seed=6) * 2).to(dt)
+    pairs = torch.stack([gu[:, :Fd], gu[:, Fd:]], dim=2).reshape(77, 2 * Fd).contiguous()
+    a, b = ops.swiglu(gu.to(DEV)), ops.swiglu_pairs(pairs.to(DEV))
+    assert torch.equal(a, b)
+    assert _rel(a, (F.silu(gu[:, :Fd].double()) * gu[:, Fd:].double())) < (2e-6 if dt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,Fd,K", [(8192 + 77, 2048, 512), (16990, 11008, 4096 // 8), (4096, 1536, 1024), (300, 512, 256)])
+def test_gate_up_linear_with_swiglu_in_its_epilogue(dt, M, Fd, K):
+    """LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) (HF modeling_llama.py, reached from setokim_llama.py:130-143) as ONE launch: the ping-pong GEMM with SwiGLU in
+    its epilogue (setok_linear_swiglu; round 6).  The epilogue keeps torch's rounding points, so the fused launch, the unfused pair
+    (setok_linear on the pair-interleaved weight + setok_swiglu_pairs) and the rows `linear_swiglu` leaves to that pair (behind the last whole 256-row tile; problems
+    too small for the persistent kernel) give IDENTICAL bits — and all of it sits within 16-bit rounding of the fp64 formula."""
+    x = _rand(M, K, seed=1).to(dt)
+    wg, wu = (_rand(Fd, K, seed=2) * K ** -0.5).to(dt), (_rand(Fd, K, seed=3) * K ** -0.5).to(dt)
+    wp = ops.interleave_gate_up(wg.to(DEV), wu.to(DEV))
+    assert torch.equal(wp[0::2].cpu(), wg) and torch.equal(wp[1::2].cpu(), wu)
+    got = ops.linear_swiglu(x.to(DEV), wp)
+    unfused = ops.swiglu_pairs(ops.linear(x.to(DEV), wp))
+    assert got.dtype == dt and got.shape == (M, Fd) and torch.equal(got, unfused)
+    classic = ops.swiglu(ops.linear(x.to(DEV), torch.cat([wg, wu], 0).to(DEV)))            # the [gate | up] layout of rounds 2-5
+    assert torch.equal(got, classic)
+    g, u = (x.double() @ wg.double().t()).to(dt).double(), (x.double() @ wu.double().t()).to(dt).double()
+    ref = F.silu(g).to(dt).double() * u
+    assert _rel(got, ref) < (1.5e-2 if dt == torch.bfloat16 else 2e-3)
+    sub = ops.linear_swiglu(x[:257].contiguous().to(DEV), wp)                               # a sample alone = the sample inside the batch
+    assert torch.equal(sub, got[:257])
+
+
 def _causal_ref(qkv, km, B, T, H, Dh):
     q, k, v = [t.reshape(B, T, H, Dh).transpose(1, 2).double() for t in qkv.double().reshape(B, T, 3, H * Dh).unbind(2)]
     allow = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None] & km.bool().reshape(B, 1, 1, T)
