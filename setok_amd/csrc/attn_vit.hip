@@ -36,6 +36,11 @@ int cu_count() {                       // of the CURRENT device
 #ifndef ATTN_O_SWAP
 #define ATTN_O_SWAP 1
 #endif
+#ifndef ATTN_DEFER_MAX
+#define ATTN_DEFER_MAX 8      // round 6: the running row maximum is raised — and the 32 output accumulators rescaled — only when some row's tile maximum exceeds it by more than this many
+#endif                        // powers of two (0 = at every rise, rounds 1-5).  The branch is per WAVE: with 32 rows a tile raised SOME row's maximum almost every time, so nearly every
+                              // tile paid 16 packed multiplies + an exp; with the threshold a query tile rescales once, after its first key tile.  Probabilities then reach 2^8 instead
+                              // of 1 — nothing for an fp32 sum, a bf16 / fp16 P operand or the final division; the result's bits change within rounding.
 #ifndef ATTN_SHORT_TAIL
 #define ATTN_SHORT_TAIL 1     // 1 (round 6): a last key tile with at most 8 valid keys (T = 257 / 577: ONE — every ViT with a class token; T = 197: 5) runs a short form of
 #endif                        // the softmax step — 4 of the 16 score registers, one of the two PV k-steps — instead of exponentiating 15 masked scores per lane
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
 
     const int qi = lane & 31, hi = lane >> 5;
     const int nq = (Tq + 31) >> 5, nkv = Tp >> 5;
+    const float defer_raw = (float)ATTN_DEFER_MAX / scale_log2e;        // the threshold in raw score units
     // transposing-read address pattern: lanes 4j+p of a 16-lane group supply row j, 4-column piece p
     const int g16 = lane >> 4, i16 = lane & 15;
     const int tr_row = (i16 >> 2) + 4 * (g16 >> 1);            // + 4*hi
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
                 for (int r = 0; r < 4; ++r) { t[r] = (r + 4 * hi < nvalid) ? s[r] : -INFINITY; mx = fmaxf(mx, t[r]); }
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run, mx);
-                if (!__all(m_new == m_run)) {
+                if (ATTN_DEFER_MAX ? __any(mx > m_run + defer_raw) : !__all(m_new == m_run)) {
                     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
                     l_run *= alpha;
 #pragma unroll
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void attn_vit_kernel(const bf16* __restric
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            if (!__all(m_new == m_run)) {                 // wave-uniform: most tiles after the first few do not raise any row max
+            if (ATTN_DEFER_MAX ? __any(mx > m_run + defer_raw) : !__all(m_new == m_run)) {      // wave-uniform (see ATTN_DEFER_MAX)
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
                 l_run *= alpha;
 #pragma unroll
