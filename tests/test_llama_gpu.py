@@ -32,7 +32,7 @@ def _rel(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3), (torch.float16, 8e-3)])
 def test_rmsnorm(dt, tol):
     x, w = (_rand(37, 256, seed=1) * 3).to(dt), (1 + 0.1 * _rand(256, seed=2)).to(dt)
     ref = O.llama_rmsnorm(x.float().to(dt), w, 1e-5)
@@ -42,7 +42,7 @@ def test_rmsnorm(dt, tol):
         assert float((got.cpu().float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2), (torch.float16, 1e-2)])
 def test_rope(dt, tol):
     rows, H, Dh = 50, 3, 32
     qkv = _rand(rows, 3 * H * Dh, seed=3).to(dt)
@@ -55,7 +55,7 @@ def test_rope(dt, tol):
     assert torch.equal(got[:, 2 * H * Dh:], qkv[:, 2 * H * Dh:])            # v untouched
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3), (torch.float16, 8e-3)])
 def test_swiglu(dt, tol):
     gu = (_rand(33, 2 * 176, seed=5) * 2).to(dt)
     ref = F.silu(gu[:, :176]) * gu[:, 176:]
@@ -214,7 +214,7 @@ def test_setokim_forward_splices_then_prefills():
     assert _rel(lg.cpu()[ram.bool()], ref[ram.bool()]) < 1e-4
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-6)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-6), (torch.float16, 2e-6)])
 def test_lm_loss_matches_oracle_and_golden(golden_dir, dt, tol):
     """setok_lm_loss against the oracle (setokim_llama.py:145-160) and, in fp32, the reference's own value; the logits are bf16-representable, so
     both dtypes read the same numbers.  Also: a strided logits view, no valid position -> NaN, and the count."""
@@ -251,7 +251,7 @@ def test_prefill_returns_the_lm_loss():
         m(inputs_embeds=x, attention_mask=am.to(DEV), return_loss=True)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("V", [97, 99, 32003 // 100])
 def test_lm_loss_resized_vocabulary_contiguous_rows(dt, V):
     """`initialize_vision_tokenizer` resizes the vocabulary when it adds the image tokens (32002, 32003, ...): contiguous logits rows then start

@@ -125,7 +125,7 @@ def test_linear_transpose_detecting():
 # ---------------------------------------------------------------------------------------------
 # layernorm / attention
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3), (torch.float16, 8e-3)])
 @pytest.mark.parametrize("rows,C", [(5, 64), (1028, 1024), (33, 768), (7776, 768), (4500, 1280), (1030, 512), (3100, 2048), (5000, 1024), (3000, 1536)])
 def test_layernorm(dt, tol, rows, C):
     x = (_rand(rows, C, seed=5) * 3 + 0.5).to(dt)
@@ -153,7 +153,7 @@ def _attn_ref(qkv, H, Dh, scale, offsets):
     return out
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2), (torch.float16, 1e-2)])
 @pytest.mark.parametrize("T,H,Dh,nimg", [(17, 4, 16, 3), (257, 16, 64, 2), (65, 2, 512, 2), (197, 12, 64, 1), (324, 16, 48, 2), (33, 3, 48, 3),
                                           (256, 12, 64, 2), (577, 16, 64, 1), (40, 2, 96, 2),
                                           (300, 16, 64, 1), (1, 2, 64, 2), (608, 4, 64, 1), (289, 16, 48, 1), (9, 2, 64, 2), (41, 2, 64, 2)])
@@ -164,7 +164,7 @@ def test_attention_uniform(dt, tol, T, H, Dh, nimg):
     assert _rel_err(got, ref) < tol
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2), (torch.float16, 1e-2)])
 def test_attention_ragged(dt, tol):
     H, Dh = 2, 32
     lens = [1, 7, 64, 3, 1, 129, 20]
@@ -188,7 +188,7 @@ def _cross_ref(q, k, v, H, Dh, scale, q_len, offs):
     return out
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1e-2), (torch.float16, 1e-2)])
 @pytest.mark.parametrize("H,Dh,q_len,lens", [(4, 16, 25, [7, 3, 1, 12]), (12, 64, 256, [37, 24, 1, 64, 65]), (12, 64, 324, [40, 33]),
                                              (2, 64, 5, [130, 2]), (3, 96, 16, [9, 70]), (12, 64, 33, [50, 17, 1]), (4, 64, 257, [8, 9, 31, 32, 33])])
 def test_cross_attention_ragged(dt, tol, H, Dh, q_len, lens):
@@ -244,7 +244,7 @@ def test_attention_ragged_head_dim_512_bf16(lens):
 # ---------------------------------------------------------------------------------------------
 # glue
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,p,g", [(2, 14, 4), (3, 16, 14), (1, 32, 7), (5, 2, 3), (2, 7, 5), (1, 3, 2)])
 def test_patchify_matches_conv(dt, B, p, g):
     img = _rand(B, 3, p * g, p * g, seed=10).to(dt)
@@ -257,7 +257,7 @@ def test_patchify_matches_conv(dt, B, p, g):
     assert _rel_err(got, ref) < 1e-12
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_assemble_and_select(dt):
     B, N, C = 3, 16, 64
     pe, cls, pos = _rand(B * N, C, seed=12).to(dt), _rand(C, seed=13).to(dt), _rand(N + 1, C, seed=14).to(dt)
@@ -356,7 +356,7 @@ def test_cluster_batched_equals_per_image_and_bf16_runs():
                                O.cluster_sensitivity(xb[i].float(), 8, 0.5, 64))
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,k,mcn,thr", [(1024, 256, 64, 64, 0.5), (1024, 256, 64, 64, 1e9), (4, 64, 2, 2, 0.5), (1, 64, 1, 1, 0.5), (576, 1024, 64, 64, 0.2)])
 def test_cluster_size_limits(dt, N, C, k, mcn, thr):
     """The largest supported grid (32 x 32 = 1024 patches: 64 lanes x 16 register slots per distance row), the smallest (2 x 2, and a single

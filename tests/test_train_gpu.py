@@ -35,7 +35,7 @@ def _rel(got, ref):
 
 
 # ---- the backward ops one by one -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows,cols,pad", [(5, 8, 1), (130, 96, 16), (1000, 1024, 64), (64, 72, 64)])
 def test_transpose_pads_with_zeros(dt, rows, cols, pad):
     x = _rand(rows, cols, seed=1).to(dt)
@@ -46,12 +46,12 @@ def test_transpose_pads_with_zeros(dt, rows, cols, pad):
     assert torch.equal(out2.cpu(), out) and _rel(cs, x.double().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-5)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-5), (torch.float16, 2e-5)])
 @pytest.mark.parametrize("M,N,K,S", [(5000, 96, 64, 4), (20000, 256, 128, 8), (700, 64, 64, 3)])
 def test_split_k_weight_gradient(dt, tol, M, N, K, S):
     """dW = dY^T X through the split-K layout (chunked transposes, one batched GEMM, fixed-order sum) == the plain product."""
     dy, x = _rand(M, N, seed=20).to(dt), _rand(M, K, seed=21).to(dt)
-    pad = 64 if dt == torch.bfloat16 else 16
+    pad = 16 if dt == torch.float32 else 64
     aT, bT = ops.transpose(dy.to(DEV), pad, S), ops.transpose(x.to(DEV), pad, S)
     assert aT.shape[0] == S and aT.shape[1] == N and aT.shape[2] % pad == 0
     got = ops.linear_tn(aT, bT)
@@ -60,7 +60,7 @@ def test_split_k_weight_gradient(dt, tol, M, N, K, S):
     assert torch.equal(got, again)
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-5)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-5), (torch.float16, 1e-5)])
 def test_colsum_and_accumulate(dt, tol):
     x = _rand(3000, 200, seed=2).to(dt)
     out = ops.colsum(x.to(DEV))
@@ -69,7 +69,7 @@ def test_colsum_and_accumulate(dt, tol):
     assert _rel(out, 2 * x.double().sum(0)) < tol
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 2e-2)])
 @pytest.mark.parametrize("rows,C", [(7, 64), (1030, 1024), (33, 768)])
 def test_layernorm_bwd(dt, tol, rows, C):
     x, dy, res = (_rand(rows, C, seed=3) * 2 + 0.3).to(dt), _rand(rows, C, seed=4).to(dt), _rand(rows, C, seed=5).to(dt)
@@ -84,7 +84,7 @@ def test_layernorm_bwd(dt, tol, rows, C):
     assert _rel(dg, 2 * gr.grad) < max(tol, 1e-4)
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2), (torch.float16, 1e-2)])
 def test_gelu_bwd(dt, tol):
     pre, dy = (_rand(4000, seed=7) * 2).to(dt), _rand(4000, seed=8).to(dt)
     pr = pre.double().requires_grad_(True)
@@ -92,7 +92,7 @@ def test_gelu_bwd(dt, tol):
     assert _rel(ops.gelu_bwd(pre.to(DEV), dy.to(DEV)), pr.grad) < tol
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 @pytest.mark.parametrize("H,Dh,lens", [(2, 32, [1, 7, 64, 3, 20]), (2, 512, [5, 1, 9]), (4, 16, [130, 2]), (2, 512, [40, 130, 7, 33, 64, 32, 229])])
 def test_attention_bwd_ragged(dt, tol, H, Dh, lens):
     offs = np.concatenate([[0], np.cumsum(lens)]).tolist()
@@ -114,7 +114,7 @@ def test_attention_bwd_ragged(dt, tol, H, Dh, lens):
     assert _rel(dqkv, qr.grad) < tol
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_segment_mean_bwd(dt):
     lens = [3, 1, 6, 2]
     offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
@@ -201,7 +201,7 @@ def test_trainer_step_matches_torch_adamw(golden_dir):
 
 
 # ---- training-mode dropout (module.py:36,44,45,59,72) ------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_dropout_op_is_a_seeded_bernoulli_mask(dt):
     """setok_dropout: keep-rate 1 - p (within 5 sigma), survivors scaled by 1 / (1 - p), a pure function of (seed, offset + i) — the same call on
     a gradient is the backward pass —, residual form, in-place form."""
@@ -229,7 +229,7 @@ def test_dropout_op_is_a_seeded_bernoulli_mask(dt):
         ops.dropout(x, 1.0, seed=1)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_fused_dropout_passes_equal_the_two_launch_forms(dt):
     """Round 4: drop(act(x)) and gelu'(pre) * drop(dy) as ONE pass each (the Mlp's middle dropout, module.py:41,44): the intermediate is rounded to
     the storage type exactly as the two-launch forms round it — identical bits, at aligned and unaligned counter offsets, with a ragged tail."""
@@ -330,22 +330,24 @@ def test_trainer_dropout_policies(golden_dir):
         head_forward_train(tok, hidden.to(DEV), 2, threshold=thr, dropout_seed=1)
 
 
-def test_training_step_bf16_runs_and_reduces_loss():
-    """bf16 throughput mode at ViT-ish head dims: a few steps on a fixed batch against a fixed linear probe lower the loss."""
+@pytest.mark.parametrize("low", [torch.bfloat16, torch.float16])
+def test_training_step_bf16_runs_and_reduces_loss(low):
+    """bf16 throughput mode (and fp16: what the reference's launches without --bf16 train in, train_setokim.py:326) at ViT-ish head dims: a few steps on a fixed
+    batch against a fixed linear probe lower the loss."""
     C, N, B = 256, 64, 8
     vc = dict(hidden_size=C, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, image_size=112, patch_size=14)
     tok = SetokTokenizer(vision_tower=vc, mm_vision_select_layer=-2, hidden_dim=C, token_feat_dim=128, min_cluster_num=8,
-                         threshold=0.5, nheads=2, dim_feedforward=512).to(device=DEV, dtype=torch.bfloat16).eval()
+                         threshold=0.5, nheads=2, dim_feedforward=512).to(device=DEV, dtype=low).eval()
     tr = HeadTrainer(tok, lr=2e-3, dropout="eval")
     g = torch.Generator().manual_seed(0)
-    hidden = torch.randn(B * (N + 1), C, generator=g).to(device=DEV, dtype=torch.bfloat16)
+    hidden = torch.randn(B * (N + 1), C, generator=g).to(device=DEV, dtype=low)
     losses = []
     for _ in range(6):
         tokens, ctx = head_forward_train(tok, hidden, B)
         target = torch.ones_like(tokens.packed, dtype=torch.float32) * 0.5
         diff = tokens.packed.float() - target
         losses.append(float((diff ** 2).mean()))
-        tr.backward(ctx, (2.0 * diff / diff.numel()).to(torch.bfloat16))
+        tr.backward(ctx, (2.0 * diff / diff.numel()).to(low))
         tr.step()
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
