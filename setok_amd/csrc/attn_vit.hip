@@ -622,7 +622,7 @@ int setok_attention_vit_bf16(hipStream_t s, const bf16* qkv, bf16* out, int n_im
     // fit two per CU (16 waves at 125 VGPRs), 9-wave ones only one: measured 202 vs 242 us per layer.  (Splitting the
     // class-token tile's keys across the 8 waves and merging partial softmaxes through LDS was tried: no gain — the
     // kernel is bound by aggregate VALU/LDS issue, not by the longest wave.)
-    if (one_wg && nq >= 13) return launch<12, 64>(s, qkv, out, n_imgs, T, H, scale);   // T = 577 (19 tiles, one workgroup per CU): 12 waves 372 us, 16: 373, 10: 405, 8: 394
+    if (one_wg && nq >= 13) return launch<12, 64>(s, qkv, out, n_imgs, T, H, scale);   // T = 577 (19 tiles, one workgroup per CU): 12 waves 372 us, 16: 373, 10: 405, 8: 394 (round 3); re-swept after round 6's key-loop changes: 12: 332, 16: 333, 14: 357, 10: 367
     if (nq >= 9) return launch<8, 64>(s, qkv, out, n_imgs, T, H, scale);
     if (nq >= 7) return launch<7, 64>(s, qkv, out, n_imgs, T, H, scale);
     if (nq >= 4) return launch<4, 64>(s, qkv, out, n_imgs, T, H, scale);
